@@ -1,0 +1,148 @@
+/*
+ * bbk.h -- C ABI of the MI355X k-mer counting / de Bruijn graph construction engine.
+ *
+ * The reference (SPAdes 3.15.4 fork, /root/reference/assembler/src) has no FFI layer; its
+ * boundaries for this path are two argv contracts, a C++ operator API and two file formats
+ * (SURVEY.md 8b).  Each entry point below names the reference interface it replaces
+ * (paths relative to /root/reference/assembler/src).  All functions return 0 on success or a
+ * negative bbk_status; the message is available from bbk_last_error() (thread local).
+ * No exceptions cross the ABI.  Handles are opaque.  One context per GPU per host thread;
+ * a context is not re-entrant (same contract as KMerSortingSplitter, whose per-thread
+ * buffers make Split() one-call-at-a-time: common/utils/kmer_mph/kmer_splitter.hpp:111-118).
+ *
+ * Pointers named d_* must be device (HBM) pointers, h_* host pointers; `dst` pointers of the
+ * export calls may be either (hipMemcpyDefault).
+ */
+#ifndef BBK_H_
+#define BBK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bbk_ctx bbk_ctx;
+typedef struct bbk_reads bbk_reads;       /* 2-bit packed reads resident in HBM                     */
+typedef struct bbk_kmerset bbk_kmerset;   /* sorted distinct k-mers (+ multiplicities) in HBM       */
+typedef struct bbk_extindex bbk_extindex; /* sorted canonical k-mers + InOutMask byte each, in HBM  */
+typedef struct bbk_unitigs bbk_unitigs;   /* condensed edges + link records (host + device)         */
+
+enum bbk_status {
+    BBK_OK = 0,
+    BBK_ERR_ARG = -1,      /* bad argument (k out of [1,128), even k for the graph, ...)            */
+    BBK_ERR_HIP = -2,      /* a HIP runtime call failed (FATAL_ERROR analogue, utils/logger/logger.hpp:177-190) */
+    BBK_ERR_NOMEM = -3,
+    BBK_ERR_INTERNAL = -4, /* a device-side invariant failed (VERIFY analogue, utils/verify.hpp)      */
+    BBK_ERR_IO = -5
+};
+
+#define BBK_MAX_K 128 /* cmake/options.cmake:55-56 SPADES_MAX_K; k must be < BBK_MAX_K */
+
+/* ---- context ---------------------------------------------------------------------------- */
+const char *bbk_last_error(void);
+const char *bbk_version(void);
+int bbk_ctx_create(int device, bbk_ctx **out);
+int bbk_ctx_destroy(bbk_ctx *ctx);
+/* Run all kernels of this context on an existing hipStream_t (e.g. torch's current stream). */
+int bbk_ctx_set_stream(bbk_ctx *ctx, void *hip_stream);
+int bbk_ctx_synchronize(bbk_ctx *ctx);
+/* Accumulated HIP-event time (ms) and launch count of one named kernel family since the last
+ * reset ("extract", "hist", "scan", "scatter", "unique", "expand", "mask", "walk", ...).
+ * Timing is only recorded while profiling is enabled (it serialises nothing: events are
+ * recorded on the context's stream around each launch). */
+int bbk_ctx_profile_enable(bbk_ctx *ctx, int on);
+int bbk_ctx_profile_reset(bbk_ctx *ctx);
+int bbk_ctx_profile_get(bbk_ctx *ctx, const char *family, double *ms_total, uint64_t *launches,
+                        double *bytes_total);
+
+/* ---- reads: replaces io::EasyStream(file, followed_by_rc=true, handle_Ns=true)
+ *      (common/io/reads/io_helper.cpp:19-32) and the binary read cache
+ *      (common/io/reads/binary_converter.cpp:50-113) --------------------------------------- */
+/* ASCII reads (concatenated; offsets has n+1 entries).  Applies the LongestValid rule
+ * (common/io/reads/longest_valid_wrapper.hpp:15-52), accepts ACGTacgt (common/sequence/nucl.hpp:45-62),
+ * packs 2 bits/base (A=0 C=1 G=2 T=3, base i in bits 2(i%32) of word i/32, every read starts on
+ * a 64-bit word) and uploads.  Reverse complements are NOT materialised: kernels canonicalise. */
+int bbk_reads_from_ascii(bbk_ctx *ctx, const char *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+                         bbk_reads **out);
+/* Adopt packed reads already in HBM (not copied, not freed): d_words[u64], d_word_off[u64, n+1]
+ * (first word of each read), d_len[u32, n] (bases). */
+int bbk_reads_from_device(bbk_ctx *ctx, const void *d_words, const void *d_word_off, const void *d_len,
+                          uint64_t n_reads, uint64_t n_words, bbk_reads **out);
+/* Synthetic reads generated on the device: uniform genome of genome_len bases
+ * (seed_genome), uniform start, strand flip p=0.5, substitution rate sub_rate (seed_reads). */
+int bbk_reads_synth(bbk_ctx *ctx, uint64_t n_reads, uint32_t read_len, uint64_t genome_len, double sub_rate,
+                    uint64_t seed_genome, uint64_t seed_reads, bbk_reads **out);
+uint64_t bbk_reads_count(const bbk_reads *r);
+uint64_t bbk_reads_bases(const bbk_reads *r);
+/* Copy read i back as ASCII (tests); dst must hold len+1 bytes; returns the length via *len. */
+int bbk_reads_get_ascii(bbk_ctx *ctx, const bbk_reads *r, uint64_t i, char *h_dst, uint32_t cap, uint32_t *len);
+/* All reads back as ASCII (h_bases may be NULL to query sizes: h_offsets[n] = total bases). */
+int bbk_reads_export_ascii(bbk_ctx *ctx, const bbk_reads *r, char *h_bases, uint64_t *h_offsets, uint64_t cap_bases);
+void bbk_reads_free(bbk_reads *r);
+
+/* ---- k-mer counting: replaces kmers::KMerDiskCounter<RtSeq>::Count / CountAll
+ *      (common/utils/kmer_mph/kmer_index_builder.hpp:195-217,241-279) over a
+ *      KMerSortingSplitter (kmer_splitter.hpp:24-52,73-167) ------------------------------- */
+#define BBK_BOTH_STRANDS 1u /* spades-kmercount semantics: k-mers of reads and of rc(reads)
+                               (projects/kmercount/main.cpp:64-82,106) */
+#define BBK_CANONICAL 2u    /* only IsMinimal k-mers (utils/ph_map/storing_traits.hpp:90-101), as the
+                               gbuilder splitters use (kmer_splitters.hpp:25-41) */
+#define BBK_WITH_COUNTS 4u  /* keep multiplicities (occurrences over reads + rc(reads)) */
+int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, bbk_kmerset **out);
+/* Sort + unique an array of k-mer records already in HBM (n records of bbk_words(k) u64 each,
+ * optional u32 multiplicities that are summed).  Used after the multi-GPU exchange. */
+int bbk_kmerset_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, unsigned k,
+                            bbk_kmerset **out);
+unsigned bbk_words(unsigned k); /* RtSeq::GetDataSize (common/sequence/rtseq.hpp:129-131) */
+uint64_t bbk_kmerset_size(const bbk_kmerset *s);
+unsigned bbk_kmerset_k(const bbk_kmerset *s);
+uint64_t bbk_kmerset_instances(const bbk_kmerset *s); /* k-mer instances that entered the sort */
+#define BBK_ORDER_SORTED 0u              /* ascending, word 0 most significant (adt/array_vector.hpp:114-123) */
+#define BBK_ORDER_REFERENCE_BUCKETS16 1u /* the final_kmers order: XXH3 bucket (16) major, ascending inside
+                                            (kmer_buckets.hpp:28-33, kmer_index_builder.hpp:168-181) */
+/* dst_keys: size * words u64 (host or device); dst_counts (u32, may be NULL). */
+int bbk_kmerset_export(bbk_ctx *ctx, const bbk_kmerset *s, unsigned order, void *dst_keys, void *dst_counts);
+/* Multi-GPU owner partition: owner(key) = mulhi(mix(key), nranks).  Writes the
+ * records grouped by owner to dst (host or device) and the per-owner record counts to h_counts. */
+int bbk_kmerset_export_by_owner(bbk_ctx *ctx, const bbk_kmerset *s, unsigned nranks, void *dst_keys,
+                                void *dst_counts, uint64_t *h_counts);
+void bbk_kmerset_free(bbk_kmerset *s);
+/* Writes <path> in the final_kmers format (raw little-endian records, no header). */
+int bbk_kmerset_write_final_kmers(bbk_ctx *ctx, const bbk_kmerset *s, const char *path);
+
+/* ---- extension index: replaces DeBruijnExtensionIndexBuilder::BuildExtensionIndexFromStream
+ *      (common/utils/extension_index/kmer_extension_index_builder.hpp:62-106) -------------- */
+int bbk_extindex_build(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, bbk_extindex **out);
+uint64_t bbk_extindex_size(const bbk_extindex *x);
+unsigned bbk_extindex_k(const bbk_extindex *x);
+/* sorted canonical k-mers (size*words u64) and their InOutMask bytes
+ * (kmer_extension_index.hpp:42-196: bits 0-3 outgoing A,C,G,T; bits 4-7 incoming) */
+int bbk_extindex_export(bbk_ctx *ctx, const bbk_extindex *x, void *dst_keys, void *dst_masks);
+void bbk_extindex_free(bbk_extindex *x);
+
+/* ---- unitigs + graph links: replaces UnbranchingPathExtractor::ExtractUnbranchingPathsAndLoops
+ *      and FastGraphFromSequencesConstructor::ConstructGraph
+ *      (common/assembly_graph/construction/debruijn_graph_constructor.hpp:182-388,390-518) ----- */
+int bbk_unitigs_build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs **out);
+uint64_t bbk_unitigs_count(const bbk_unitigs *u);
+uint64_t bbk_unitigs_loops(const bbk_unitigs *u);
+uint64_t bbk_unitigs_total_bases(const bbk_unitigs *u);
+uint64_t bbk_unitigs_vertices(const bbk_unitigs *u);
+uint64_t bbk_unitigs_links(const bbk_unitigs *u);
+/* h_bases: total_bases ASCII bytes (no separators); h_offsets: count+1 entries. */
+int bbk_unitigs_export(bbk_ctx *ctx, const bbk_unitigs *u, char *h_bases, uint64_t *h_offsets);
+/* links: 4 x u32 per link (from_unitig, from_orient(1='+'), to_unitig, to_orient) */
+int bbk_unitigs_export_links(bbk_ctx *ctx, const bbk_unitigs *u, uint32_t *h_links);
+/* GFA1 text as GFAWriter::WriteSegmentsAndLinks (common/io/graph/gfa_writer.cpp:18-52), segment
+ * ids 3+2i (assembly_graph/core/graph_core.hpp:228,610-624); `--unitigs` FASTA as
+ * projects/gbuilder/main.cpp:183-192. */
+int bbk_unitigs_write_gfa(bbk_ctx *ctx, const bbk_unitigs *u, const char *path);
+int bbk_unitigs_write_fasta(bbk_ctx *ctx, const bbk_unitigs *u, const char *path);
+void bbk_unitigs_free(bbk_unitigs *u);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBK_H_ */

@@ -1,0 +1,226 @@
+// bbk_internal.h -- host-side plumbing shared by the HIP translation units (context, errors,
+// device buffers, per-kernel-family HIP-event timing).  Not part of the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/bbk.h"
+
+namespace bbk {
+
+void set_error(const char *fmt, ...);
+
+struct Error {
+    int code;
+};
+
+#define BBK_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            ::bbk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                             __LINE__);                                                        \
+            throw ::bbk::Error{BBK_ERR_HIP};                                                   \
+        }                                                                                      \
+    } while (0)
+
+#define BBK_REQUIRE(cond, code, ...)         \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::bbk::set_error(__VA_ARGS__);   \
+            throw ::bbk::Error{code};        \
+        }                                    \
+    } while (0)
+
+// Runs f(), maps exceptions to a status code: no exception crosses the C ABI.
+template <class F>
+int guarded(F &&f) {
+    try {
+        f();
+        return BBK_OK;
+    } catch (const Error &e) {
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        set_error("host allocation failed");
+        return BBK_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        set_error("internal error: %s", e.what());
+        return BBK_ERR_INTERNAL;
+    }
+}
+
+// Owning device buffer.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t n) { alloc(n); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) {
+        o.p = nullptr;
+        o.bytes = 0;
+    }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p;
+            bytes = o.bytes;
+            o.p = nullptr;
+            o.bytes = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+            throw Error{e == hipErrorOutOfMemory ? BBK_ERR_NOMEM : BBK_ERR_HIP};
+        }
+        bytes = n;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T *as() const {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
+struct FamilyStat {
+    double ms = 0;
+    uint64_t launches = 0;
+    double bytes = 0;
+};
+
+}  // namespace bbk
+
+struct bbk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    int num_cus = 256;
+    // pending (start, stop, family, bytes) event pairs; resolved lazily
+    struct Pending {
+        hipEvent_t a, b;
+        std::string family;
+        double bytes;
+    };
+    std::vector<Pending> pending;
+    std::map<std::string, bbk::FamilyStat> stats;
+    void resolve_pending();
+};
+
+namespace bbk {
+
+// RAII timer around one kernel launch (or a short run of launches) of a named family.
+struct KernelTimer {
+    bbk_ctx *ctx;
+    hipEvent_t a = nullptr, b = nullptr;
+    std::string family;
+    double bytes;
+    KernelTimer(bbk_ctx *c, const char *fam, double algorithmic_bytes = 0) : ctx(c), family(fam), bytes(algorithmic_bytes) {
+        if (ctx->profiling) {
+            BBK_HIP(hipEventCreate(&a));
+            BBK_HIP(hipEventCreate(&b));
+            BBK_HIP(hipEventRecord(a, ctx->stream));
+        }
+    }
+    ~KernelTimer() {
+        if (a) {
+            (void)hipEventRecord(b, ctx->stream);
+            ctx->pending.push_back({a, b, family, bytes});
+        }
+    }
+};
+
+inline void check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("kernel launch %s failed: %s", what, hipGetErrorString(e));
+        throw Error{BBK_ERR_HIP};
+    }
+}
+
+inline unsigned words_of(unsigned k) { return (k + 31) >> 5; }
+
+// ---- primitives.hip -------------------------------------------------------------------------
+// One LSD pass selector: kind 0 = bits [shift, shift+bits) of key word `word`;
+// kind 1 = XXH3 bucket (kmer_buckets.hpp:28-33) with nb <= 256 buckets;
+// kind 2 = owner(mix(key), nb) for the multi-GPU partition.
+struct PassDesc {
+    int kind;
+    int word;
+    int shift;
+    int bits;
+    unsigned nb;
+};
+
+// Key-bit passes that sort records of W words into the reference order (word 0 most
+// significant, adt/array_vector.hpp:114-123) given that only the low 2k bits are populated.
+std::vector<PassDesc> key_passes(unsigned k);
+
+// Stable LSD radix sort of n records (W u64 words each, optional u32 payload). keys/vals are
+// sorted in place; tmp buffers must hold n records.  n < 2^32.
+void sort_records(bbk_ctx *ctx, int W, void *keys, void *keys_tmp, uint32_t *vals, uint32_t *vals_tmp, uint64_t n,
+                  const std::vector<PassDesc> &passes);
+// Per-bin record counts of one pass (256 bins, written to h_counts), e.g. bucket sizes.
+void digit_histogram(bbk_ctx *ctx, int W, const void *keys, uint64_t n, PassDesc pd, uint64_t *h_counts);
+
+enum ReduceOp { REDUCE_COUNT = 0, REDUCE_SUM = 1, REDUCE_OR = 2 };
+// Unique of a sorted record array: distinct keys to out_keys (may alias nothing), per-key reduction of
+// vals (COUNT: run length, SUM: sum of vals, OR: or of vals) to out_vals (may be null for COUNT-less).
+// Returns the number of distinct keys.  drop_zero: omit keys whose reduced value is 0 (OR mode).
+uint64_t unique_records(bbk_ctx *ctx, int W, const void *keys, const uint32_t *vals, uint64_t n, void *out_keys,
+                        uint32_t *out_vals, ReduceOp op, bool drop_zero);
+// Exclusive scan of n u64 values (in place allowed); returns the total.
+uint64_t exclusive_scan_u64(bbk_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n);
+
+}  // namespace bbk
+
+struct bbk_reads {
+    bbk_ctx *ctx = nullptr;
+    uint64_t n = 0;        // reads
+    uint64_t n_words = 0;  // packed words
+    uint64_t bases = 0;    // total bases (sum of len)
+    const uint64_t *d_words = nullptr;
+    const uint64_t *d_woff = nullptr;  // n+1
+    const uint32_t *d_len = nullptr;   // n
+    bbk::DevBuf own_words, own_woff, own_len;
+};
+
+struct bbk_kmerset {
+    unsigned k = 0, W = 0;
+    unsigned flags = 0;
+    uint64_t n = 0;          // distinct records
+    uint64_t instances = 0;  // k-mer instances that entered the sort
+    bbk::DevBuf keys;        // n * W u64, ascending
+    bbk::DevBuf counts;      // n u32 (optional)
+    bool has_counts = false;
+};
+
+struct bbk_extindex {
+    unsigned k = 0, W = 0;
+    uint64_t n = 0;
+    uint64_t instances = 0;
+    bbk::DevBuf keys;   // n * W u64 ascending (canonical k-mers)
+    bbk::DevBuf masks;  // n u8
+    bbk::DevBuf prefix; // lookup accelerator: (1<<prefix_bits)+1 u32
+    unsigned prefix_bits = 0;
+};

@@ -1,0 +1,367 @@
+// count.hip -- k-mer extraction + counting on the device, and the bbk_kmerset part of the C ABI.
+//
+// Replaces, for one batch of reads resident in HBM:
+//   BufferFiller::operator()            reference projects/kmercount/main.cpp:64-82
+//   DeBruijnKMerSplitter::FillBufferFromSequence  common/utils/kmer_mph/kmer_splitters.hpp:25-41
+//   KMerSortingSplitter::DumpBuffers    common/utils/kmer_mph/kmer_splitter.hpp:120-167 (sort + unique)
+//   KMerDiskCounter::Count / MergeKMers common/utils/kmer_mph/kmer_index_builder.hpp:241-267,281-365
+//   KMerDiskStorage::merge              kmer_index_builder.hpp:168-181 (the final_kmers order)
+// The reference materialises both strands (RCWrap) and filters with IsMinimal; here every read
+// position yields ONE canonical key (min(kmer, rc) in base order, rtseq.hpp:407-415) and the
+// both-strand set of spades-kmercount is recovered from the distinct canonical keys as
+// canon U rc(canon)  (SURVEY.md 7.4).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "bbk_internal.h"
+#include "kmer_ops.h"
+
+namespace bbk {
+
+__global__ void k_kmers_per_read(const uint32_t *__restrict__ len, uint64_t n, uint32_t k,
+                                 uint64_t *__restrict__ nk) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t L = len[i];
+        nk[i] = L >= k ? (uint64_t)(L - k + 1) : 0ull;
+    }
+}
+
+// One wavefront per read, lanes over k-mer positions: stores of one wave are 64 consecutive
+// records.  MODE 0: canonical key.  MODE 1: canonical key + InOutMask bits of this occurrence
+// (kmer_extension_index.hpp:67-69,92-106: a non-minimal k-mer stores position 7-pos).
+template <int W, int MODE>
+__global__ __launch_bounds__(256) void k_extract(const uint64_t *__restrict__ words,
+                                                const uint64_t *__restrict__ woff,
+                                                const uint32_t *__restrict__ len,
+                                                const uint64_t *__restrict__ koff, uint64_t n_reads, int k,
+                                                Key<W> *__restrict__ out, uint32_t *__restrict__ out_val) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += nwaves) {
+        const uint32_t L = len[r];
+        if (L < (uint32_t)k) continue;
+        const uint32_t nk = L - (uint32_t)k + 1;
+        const uint64_t *rw = words + woff[r];
+        const uint64_t base = koff[r];
+        for (uint32_t p = lane; p < nk; p += 64) {
+            const Key<W> fwd = kmer_extract<W>(rw, p, k);
+            const Key<W> rc = kmer_rc<W>(fwd, k);
+            const bool minimal = !kmer_less_nucl<W>(rc, fwd);  // fwd <= rc (palindrome -> minimal)
+            out[base + p] = key_select<W>(minimal, fwd, rc);
+            if (MODE == 1) {
+                uint32_t m = 0;
+                if (p + (uint32_t)k < L) {  // (k+1)-mer starting at p: outgoing base of this k-mer
+                    const uint32_t c = base_at(rw, p + (uint32_t)k);
+                    m |= 1u << (minimal ? c : 7u - c);
+                }
+                if (p >= 1) {  // (k+1)-mer starting at p-1: incoming base
+                    const uint32_t c = base_at(rw, p - 1);
+                    m |= 1u << (minimal ? 4u + c : 3u - c);
+                }
+                out_val[base + p] = m;
+            }
+        }
+    }
+}
+
+// out[2i] = key, out[2i+1] = rc(key): the both-strand set of spades-kmercount
+template <int W>
+__global__ __launch_bounds__(256) void k_expand_rc(const Key<W> *__restrict__ in, const uint32_t *__restrict__ cin,
+                                                  uint64_t n, int k, Key<W> *__restrict__ out,
+                                                  uint32_t *__restrict__ cout) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Key<W> x = in[i];
+    out[2 * i] = x;
+    out[2 * i + 1] = kmer_rc<W>(x, k);
+    if (cin) {
+        const uint32_t c = cin[i];
+        cout[2 * i] = c;
+        cout[2 * i + 1] = c;
+    }
+}
+
+template <int W>
+static void launch_extract(bbk_ctx *ctx, const bbk_reads *rd, const uint64_t *koff, int k, void *out, uint32_t *vals,
+                           uint64_t n_inst) {
+    const unsigned blocks = (unsigned)std::min<uint64_t>((rd->n + 3) / 4, (uint64_t)ctx->num_cus * 32);
+    KernelTimer t(ctx, "extract", (double)rd->n_words * 8 + (double)n_inst * (sizeof(Key<W>) + (vals ? 4 : 0)));
+    if (vals)
+        hipLaunchKernelGGL((k_extract<W, 1>), dim3(blocks ? blocks : 1), dim3(256), 0, ctx->stream, rd->d_words,
+                           rd->d_woff, rd->d_len, koff, rd->n, k, (Key<W> *)out, vals);
+    else
+        hipLaunchKernelGGL((k_extract<W, 0>), dim3(blocks ? blocks : 1), dim3(256), 0, ctx->stream, rd->d_words,
+                           rd->d_woff, rd->d_len, koff, rd->n, k, (Key<W> *)out, (uint32_t *)nullptr);
+    check_launch("k_extract");
+}
+
+template <int W>
+static void launch_expand(bbk_ctx *ctx, const void *in, const uint32_t *cin, uint64_t n, int k, void *out,
+                          uint32_t *cout) {
+    if (n == 0) return;
+    KernelTimer t(ctx, "expand", 3.0 * (double)n * sizeof(Key<W>));
+    hipLaunchKernelGGL(k_expand_rc<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const Key<W> *)in, cin, n, k, (Key<W> *)out, cout);
+    check_launch("k_expand_rc");
+}
+
+#define BBK_DISPATCH_W(W, ...)                                                   \
+    switch (W) {                                                                 \
+        case 1: { constexpr int W_ = 1; __VA_ARGS__; } break;                           \
+        case 2: { constexpr int W_ = 2; __VA_ARGS__; } break;                           \
+        case 3: { constexpr int W_ = 3; __VA_ARGS__; } break;                           \
+        case 4: { constexpr int W_ = 4; __VA_ARGS__; } break;                           \
+        default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %d", (int)(W)); \
+    }
+
+// Extract one record per k-mer position, sort, reduce.  Result: distinct canonical keys
+// (ascending) + payload (COUNT: multiplicity; OR: InOutMask).  Shared with extindex.hip.
+void count_canonical(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_mask, bool want_vals, DevBuf &out_keys,
+                     DevBuf &out_vals, uint64_t &n_distinct, uint64_t &n_instances) {
+    const int W = (int)words_of(k);
+    n_distinct = 0;
+    n_instances = 0;
+    DevBuf koff((rd->n + 1) * sizeof(uint64_t));
+    if (rd->n) {
+        hipLaunchKernelGGL(k_kmers_per_read, dim3((unsigned)((rd->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           rd->d_len, rd->n, k, koff.as<uint64_t>());
+        check_launch("k_kmers_per_read");
+    }
+    const uint64_t N = exclusive_scan_u64(ctx, koff.as<uint64_t>(), koff.as<uint64_t>(), rd->n);
+    n_instances = N;
+    if (N == 0) {
+        out_keys.alloc(16);
+        out_vals.alloc(16);
+        return;
+    }
+    BBK_REQUIRE(N < (1ull << 32), BBK_ERR_ARG,
+                "batch holds %llu k-mer instances; a single device batch is limited to 2^32-1 (split the reads)",
+                (unsigned long long)N);
+    const size_t rec = (size_t)W * 8;
+    DevBuf keys(N * rec), tmp(N * rec), vals, vtmp;
+    if (with_mask) {
+        vals.alloc(N * 4);
+        vtmp.alloc(N * 4);
+    }
+    BBK_DISPATCH_W(W, launch_extract<W_>(ctx, rd, koff.as<uint64_t>(), (int)k, keys.p,
+                                         with_mask ? vals.as<uint32_t>() : nullptr, N));
+    sort_records(ctx, W, keys.p, tmp.p, with_mask ? vals.as<uint32_t>() : nullptr,
+                 with_mask ? vtmp.as<uint32_t>() : nullptr, N, key_passes(k));
+    // distinct keys land in tmp (sized for the worst case), then are copied to an exact buffer
+    uint32_t *rv = nullptr;
+    if (with_mask || want_vals) {
+        if (!vtmp.p) vtmp.alloc(N * 4);
+        rv = vtmp.as<uint32_t>();
+    }
+    const uint64_t D = unique_records(ctx, W, keys.p, with_mask ? vals.as<uint32_t>() : nullptr, N, tmp.p, rv,
+                                      with_mask ? REDUCE_OR : REDUCE_COUNT, /*drop_zero=*/with_mask);
+    keys.release();
+    vals.release();
+    out_keys.alloc(D * rec);
+    BBK_HIP(hipMemcpyAsync(out_keys.p, tmp.p, D * rec, hipMemcpyDeviceToDevice, ctx->stream));
+    if (rv) {
+        out_vals.alloc(D * 4);
+        BBK_HIP(hipMemcpyAsync(out_vals.p, rv, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    BBK_HIP(hipStreamSynchronize(ctx->stream));
+    n_distinct = D;
+}
+
+static void check_k(unsigned k) {
+    // KMerCounter accepts any k in [1, MAX_K) (projects/kmercount/main.cpp has no parity check)
+    BBK_REQUIRE(k >= 1 && k < BBK_MAX_K, BBK_ERR_ARG, "k-mer size %u out of range [1,%d)", k, BBK_MAX_K);
+}
+
+}  // namespace bbk
+
+using namespace bbk;
+
+extern "C" {
+
+int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, bbk_kmerset **out) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && reads && out, BBK_ERR_ARG, "bbk_count: NULL argument");
+        check_k(k);
+        const bool both = (flags & BBK_BOTH_STRANDS) != 0, canon = (flags & BBK_CANONICAL) != 0;
+        BBK_REQUIRE(both != canon, BBK_ERR_ARG, "bbk_count: pass exactly one of BBK_BOTH_STRANDS / BBK_CANONICAL");
+        const bool wc = (flags & BBK_WITH_COUNTS) != 0;
+        BBK_HIP(hipSetDevice(ctx->device));
+        auto s = std::make_unique<bbk_kmerset>();
+        s->k = k;
+        s->W = words_of(k);
+        s->flags = flags;
+        s->has_counts = wc;
+        DevBuf ck, cv;
+        uint64_t D = 0, N = 0;
+        count_canonical(ctx, reads, k, /*with_mask=*/false, wc, ck, cv, D, N);
+        s->instances = both ? 2 * N : N;
+        if (canon) {
+            s->n = D;
+            s->keys = std::move(ck);
+            if (wc) s->counts = std::move(cv);
+        } else if (D == 0) {
+            s->n = 0;
+            s->keys.alloc(16);
+            if (wc) s->counts.alloc(16);
+        } else {
+            const int W = (int)s->W;
+            const size_t rec = (size_t)W * 8;
+            BBK_REQUIRE(2 * D < (1ull << 32), BBK_ERR_ARG, "too many distinct k-mers for one device batch");
+            DevBuf e(2 * D * rec), et(2 * D * rec), ec, ect;
+            if (wc) {
+                ec.alloc(2 * D * 4);
+                ect.alloc(2 * D * 4);
+            }
+            BBK_DISPATCH_W(W, launch_expand<W_>(ctx, ck.p, wc ? cv.as<uint32_t>() : nullptr, D, (int)k, e.p,
+                                                wc ? ec.as<uint32_t>() : nullptr));
+            ck.release();
+            cv.release();
+            sort_records(ctx, W, e.p, et.p, wc ? ec.as<uint32_t>() : nullptr, wc ? ect.as<uint32_t>() : nullptr,
+                         2 * D, key_passes(k));
+            // a k-mer equal to its own RC (even k) appears twice: unique merges it; its count doubles,
+            // as in the reference where both strands of such an occurrence are counted
+            const uint64_t D2 = unique_records(ctx, W, e.p, wc ? ec.as<uint32_t>() : nullptr, 2 * D, et.p,
+                                               wc ? ect.as<uint32_t>() : nullptr, wc ? REDUCE_SUM : REDUCE_COUNT, false);
+            s->n = D2;
+            s->keys.alloc(D2 * rec);
+            BBK_HIP(hipMemcpyAsync(s->keys.p, et.p, D2 * rec, hipMemcpyDeviceToDevice, ctx->stream));
+            if (wc) {
+                s->counts.alloc(D2 * 4);
+                BBK_HIP(hipMemcpyAsync(s->counts.p, ect.p, D2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        *out = s.release();
+    });
+}
+
+int bbk_kmerset_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, unsigned k,
+                            bbk_kmerset **out) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && out && (n == 0 || d_keys), BBK_ERR_ARG, "bbk_kmerset_from_device: NULL argument");
+        check_k(k);
+        BBK_HIP(hipSetDevice(ctx->device));
+        auto s = std::make_unique<bbk_kmerset>();
+        s->k = k;
+        s->W = words_of(k);
+        s->has_counts = d_counts != nullptr;
+        s->instances = n;
+        const size_t rec = (size_t)s->W * 8;
+        if (n == 0) {
+            s->keys.alloc(16);
+            if (d_counts) s->counts.alloc(16);
+            *out = s.release();
+            return;
+        }
+        DevBuf a(n * rec), b(n * rec), ca, cb;
+        BBK_HIP(hipMemcpyAsync(a.p, d_keys, n * rec, hipMemcpyDeviceToDevice, ctx->stream));
+        if (d_counts) {
+            ca.alloc(n * 4);
+            cb.alloc(n * 4);
+            BBK_HIP(hipMemcpyAsync(ca.p, d_counts, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        sort_records(ctx, (int)s->W, a.p, b.p, d_counts ? ca.as<uint32_t>() : nullptr,
+                     d_counts ? cb.as<uint32_t>() : nullptr, n, key_passes(k));
+        const uint64_t D = unique_records(ctx, (int)s->W, a.p, d_counts ? ca.as<uint32_t>() : nullptr, n, b.p,
+                                          d_counts ? cb.as<uint32_t>() : nullptr,
+                                          d_counts ? REDUCE_SUM : REDUCE_COUNT, false);
+        s->n = D;
+        s->keys.alloc(D * rec);
+        BBK_HIP(hipMemcpyAsync(s->keys.p, b.p, D * rec, hipMemcpyDeviceToDevice, ctx->stream));
+        if (d_counts) {
+            s->counts.alloc(D * 4);
+            BBK_HIP(hipMemcpyAsync(s->counts.p, cb.p, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        *out = s.release();
+    });
+}
+
+uint64_t bbk_kmerset_size(const bbk_kmerset *s) { return s ? s->n : 0; }
+unsigned bbk_kmerset_k(const bbk_kmerset *s) { return s ? s->k : 0; }
+uint64_t bbk_kmerset_instances(const bbk_kmerset *s) { return s ? s->instances : 0; }
+
+static void export_ordered(bbk_ctx *ctx, const bbk_kmerset *s, const PassDesc *pd, void *dst_keys, void *dst_counts,
+                           uint64_t *h_counts) {
+    BBK_HIP(hipSetDevice(ctx->device));
+    const size_t rec = (size_t)s->W * 8;
+    if (h_counts && pd) memset(h_counts, 0, pd->nb * sizeof(uint64_t));
+    if (s->n == 0) return;
+    const bool wc = s->has_counts && dst_counts;
+    if (!pd) {
+        BBK_HIP(hipMemcpyAsync(dst_keys, s->keys.p, s->n * rec, hipMemcpyDefault, ctx->stream));
+        if (wc) BBK_HIP(hipMemcpyAsync(dst_counts, s->counts.p, s->n * 4, hipMemcpyDefault, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        return;
+    }
+    DevBuf a(s->n * rec), b(s->n * rec), ca, cb;
+    BBK_HIP(hipMemcpyAsync(a.p, s->keys.p, s->n * rec, hipMemcpyDeviceToDevice, ctx->stream));
+    if (wc) {
+        ca.alloc(s->n * 4);
+        cb.alloc(s->n * 4);
+        BBK_HIP(hipMemcpyAsync(ca.p, s->counts.p, s->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (h_counts) {
+        uint64_t hc[256];
+        digit_histogram(ctx, (int)s->W, a.p, s->n, *pd, hc);
+        for (unsigned i = 0; i < pd->nb; ++i) h_counts[i] = hc[i];
+    }
+    // one stable pass on the bucket digit keeps the ascending order inside each bucket
+    sort_records(ctx, (int)s->W, a.p, b.p, wc ? ca.as<uint32_t>() : nullptr, wc ? cb.as<uint32_t>() : nullptr, s->n,
+                 std::vector<PassDesc>{*pd});
+    BBK_HIP(hipMemcpyAsync(dst_keys, a.p, s->n * rec, hipMemcpyDefault, ctx->stream));
+    if (wc) BBK_HIP(hipMemcpyAsync(dst_counts, ca.p, s->n * 4, hipMemcpyDefault, ctx->stream));
+    BBK_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+int bbk_kmerset_export(bbk_ctx *ctx, const bbk_kmerset *s, unsigned order, void *dst_keys, void *dst_counts) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && s && (s->n == 0 || dst_keys), BBK_ERR_ARG, "bbk_kmerset_export: NULL argument");
+        BBK_REQUIRE(order == BBK_ORDER_SORTED || order == BBK_ORDER_REFERENCE_BUCKETS16, BBK_ERR_ARG,
+                    "bbk_kmerset_export: unknown order %u", order);
+        if (order == BBK_ORDER_SORTED) {
+            export_ordered(ctx, s, nullptr, dst_keys, dst_counts, nullptr);
+        } else {
+            const PassDesc pd{1, 0, 0, 8, 16};  // CountAll(16, ...) (projects/kmercount/main.cpp:215)
+            export_ordered(ctx, s, &pd, dst_keys, dst_counts, nullptr);
+        }
+    });
+}
+
+int bbk_kmerset_export_by_owner(bbk_ctx *ctx, const bbk_kmerset *s, unsigned nranks, void *dst_keys,
+                                void *dst_counts, uint64_t *h_counts) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && s && h_counts && (s->n == 0 || dst_keys), BBK_ERR_ARG,
+                    "bbk_kmerset_export_by_owner: NULL argument");
+        BBK_REQUIRE(nranks >= 1 && nranks <= 256, BBK_ERR_ARG, "bbk_kmerset_export_by_owner: nranks %u not in [1,256]",
+                    nranks);
+        const PassDesc pd{2, 0, 0, 8, nranks};
+        export_ordered(ctx, s, &pd, dst_keys, dst_counts, h_counts);
+    });
+}
+
+void bbk_kmerset_free(bbk_kmerset *s) { delete s; }
+
+int bbk_kmerset_write_final_kmers(bbk_ctx *ctx, const bbk_kmerset *s, const char *path) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && s && path, BBK_ERR_ARG, "bbk_kmerset_write_final_kmers: NULL argument");
+        const size_t rec = (size_t)s->W * 8;
+        std::vector<uint64_t> host((s->n * rec) / 8 + 1);
+        const PassDesc pd{1, 0, 0, 8, 16};
+        export_ordered(ctx, s, &pd, host.data(), nullptr, nullptr);
+        FILE *f = fopen(path, "wb");
+        BBK_REQUIRE(f != nullptr, BBK_ERR_IO, "cannot open %s for writing", path);
+        const size_t wr = fwrite(host.data(), 1, s->n * rec, f);
+        const int cl = fclose(f);
+        BBK_REQUIRE(wr == s->n * rec && cl == 0, BBK_ERR_IO, "short write to %s", path);
+    });
+}
+
+}  // extern "C"

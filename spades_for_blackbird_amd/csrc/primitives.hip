@@ -1,0 +1,754 @@
+// primitives.hip -- device-wide building blocks for the k-mer engine on gfx950:
+//   * exclusive scan (u64),
+//   * stable LSD radix sort of fixed-width k-mer records (+ optional u32 payload) with
+//     LDS-staged digit histograms, wavefront ballot match-any ranking (64-wide) and an LDS
+//     reorder so that global stores leave the CU as contiguous per-digit runs,
+//   * unique / reduce-by-key over a sorted record array.
+// They replace, on the device, what the reference does with libcxx::sort + std::unique per
+// bucket (common/utils/kmer_mph/kmer_splitter.hpp:120-167) and the loser-tree merge
+// (kmer_index_builder.hpp:281-365).  Integer/HBM-bound work: no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstring>
+
+#include "bbk_internal.h"
+#include "kmer_ops.h"
+
+namespace bbk {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char *get_error() { return g_err; }
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kRadix = 256;
+
+template <int W>
+struct SortCfg {
+    // tile sized so that static + staged LDS stays below 64 KiB for every key width
+    static constexpr int ITEMS = (W == 1) ? 16 : (W <= 3 ? 8 : 4);
+    static constexpr int TILE = kThreads * ITEMS;
+};
+
+// ------------------------------------------------------------------------------------------
+// block-wide exclusive scan of one u32 per thread (256 threads), wave shuffles + LDS
+// ------------------------------------------------------------------------------------------
+__device__ inline uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// returns the exclusive prefix of v over the block; *total receives the block sum.
+__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *smem_waves /*[kWaves+1]*/, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan(v);
+    if (lane == 63) smem_waves[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        uint32_t s = smem_waves[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of u64
+// ------------------------------------------------------------------------------------------
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kThreads * kScanItems;
+
+__global__ __launch_bounds__(kThreads) void k_scan_reduce(const uint64_t *__restrict__ in, uint64_t n,
+                                                         uint64_t *__restrict__ bsum) {
+    __shared__ uint64_t sm[kWaves];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile;
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        uint64_t idx = base + (uint64_t)i * kThreads + threadIdx.x;
+        if (idx < n) s += in[idx];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < kWaves; ++w) t += sm[w];
+        bsum[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_scan_apply(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                        uint64_t n, const uint64_t *__restrict__ boff) {
+    __shared__ uint64_t sm[kWaves];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    uint64_t v[kScanItems];
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        s += v[i];
+    }
+    // block exclusive scan of s
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) sm[wave] = incl;
+    __syncthreads();
+    uint64_t wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += sm[w];
+    uint64_t run = boff[blockIdx.x] + wbase + incl - s;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+}
+
+uint64_t exclusive_scan_u64(bbk_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n) {
+    if (n == 0) return 0;
+    const uint64_t nb = (n + kScanTile - 1) / kScanTile;
+    DevBuf bsum((nb + 1) * sizeof(uint64_t));
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream, in, n, bsum.as<uint64_t>());
+    check_launch("k_scan_reduce");
+    uint64_t total;
+    if (nb == 1) {
+        BBK_HIP(hipMemcpyAsync(&total, bsum.p, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipMemsetAsync(bsum.p, 0, sizeof(uint64_t), ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        total = exclusive_scan_u64(ctx, bsum.as<uint64_t>(), bsum.as<uint64_t>(), nb);
+    }
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream, in, out, n,
+                       bsum.as<uint64_t>());
+    check_launch("k_scan_apply");
+    BBK_HIP(hipStreamSynchronize(ctx->stream));  // bsum is freed on return
+    return total;
+}
+
+// ------------------------------------------------------------------------------------------
+// radix sort
+// ------------------------------------------------------------------------------------------
+// Digit of a record that sits in memory (global or LDS) at p.  For a key-bit pass the sort word
+// is re-read from memory with a dynamic MEMORY index: indexing the register copy with the
+// runtime pd.word would push the whole tile to scratch.
+template <int W>
+__device__ inline uint32_t digit_of(const Key<W> &key, const Key<W> *p, const PassDesc &pd) {
+    if (pd.kind == 0) {
+        const uint64_t w = (W == 1) ? key.w[0] : reinterpret_cast<const uint64_t *>(p)[pd.word];
+        return (uint32_t)(w >> pd.shift) & ((1u << pd.bits) - 1u);
+    }
+    if (pd.kind == 1) return (uint32_t)__umul64hi(xxh3_64<W>(key), (uint64_t)pd.nb);
+    return (uint32_t)__umul64hi(owner_mix<W>(key), (uint64_t)pd.nb);
+}
+
+// per-tile digit histogram -> hist[tile][256]
+template <int W>
+__global__ __launch_bounds__(kThreads) void k_hist(const Key<W> *__restrict__ in, uint64_t n, PassDesc pd,
+                                                  uint32_t *__restrict__ hist) {
+    constexpr int ITEMS = SortCfg<W>::ITEMS, TILE = SortCfg<W>::TILE;
+    __shared__ uint32_t h[kRadix];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        uint64_t idx = base + (uint64_t)i * kThreads + threadIdx.x;
+        if (idx < n) {
+            const Key<W> key = key_load<W>(&in[idx]);
+            atomicAdd(&h[digit_of<W>(key, &in[idx], pd)], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(uint64_t)blockIdx.x * kRadix + threadIdx.x] = h[threadIdx.x];
+}
+
+// column sums over chunks of kChunk tiles
+constexpr int kChunk = 256;
+__global__ __launch_bounds__(kRadix) void k_colsum(const uint32_t *__restrict__ hist, uint64_t ntiles,
+                                                  uint64_t *__restrict__ chunk_sum) {
+    const uint64_t t0 = (uint64_t)blockIdx.x * kChunk;
+    const uint64_t t1 = (t0 + kChunk < ntiles) ? t0 + kChunk : ntiles;
+    uint64_t s = 0;
+    for (uint64_t t = t0; t < t1; ++t) s += hist[t * kRadix + threadIdx.x];
+    chunk_sum[(uint64_t)blockIdx.x * kRadix + threadIdx.x] = s;
+}
+
+// single block: chunk_sum[c][d] -> exclusive global base of (chunk c, digit d) in digit-major order
+__global__ __launch_bounds__(kRadix) void k_scan_chunks(uint64_t *__restrict__ chunk_sum, uint64_t nchunks,
+                                                       uint64_t *__restrict__ digit_total) {
+    __shared__ uint64_t tot[kRadix];
+    const int d = threadIdx.x;
+    uint64_t run = 0;
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        uint64_t v = chunk_sum[c * kRadix + d];
+        chunk_sum[c * kRadix + d] = run;
+        run += v;
+    }
+    tot[d] = run;
+    if (digit_total) digit_total[d] = run;
+    __syncthreads();
+    uint64_t base = 0;
+    for (int j = 0; j < d; ++j) base += tot[j];
+    for (uint64_t c = 0; c < nchunks; ++c) chunk_sum[c * kRadix + d] += base;
+}
+
+// hist[t][d] (counts) -> global start offset of (tile t, digit d)
+__global__ __launch_bounds__(kRadix) void k_tile_offsets(uint32_t *__restrict__ hist, uint64_t ntiles,
+                                                        const uint64_t *__restrict__ chunk_base) {
+    const uint64_t t0 = (uint64_t)blockIdx.x * kChunk;
+    const uint64_t t1 = (t0 + kChunk < ntiles) ? t0 + kChunk : ntiles;
+    uint64_t run = chunk_base[(uint64_t)blockIdx.x * kRadix + threadIdx.x];
+    for (uint64_t t = t0; t < t1; ++t) {
+        uint32_t v = hist[t * kRadix + threadIdx.x];
+        hist[t * kRadix + threadIdx.x] = (uint32_t)run;
+        run += v;
+    }
+}
+
+// wavefront match-any on an 8-bit digit: mask of lanes (among `valid` lanes) holding the same digit
+__device__ inline uint64_t match_digit(uint32_t d, bool valid) {
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+template <int W, bool HAS_VAL>
+__global__ __launch_bounds__(kThreads) void k_scatter(const Key<W> *__restrict__ in, Key<W> *__restrict__ out,
+                                                     const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout,
+                                                     uint64_t n, PassDesc pd,
+                                                     const uint32_t *__restrict__ tile_off) {
+    constexpr int ITEMS = SortCfg<W>::ITEMS, TILE = SortCfg<W>::TILE;
+    __shared__ uint32_t wave_cnt[kWaves][kRadix];
+    __shared__ uint32_t digit_start[kRadix];
+    __shared__ uint32_t goff[kRadix];
+    __shared__ uint32_t scan_tmp[kWaves + 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    Key<W> *stage = reinterpret_cast<Key<W> *>(dyn_smem);
+    uint32_t *vstage = reinterpret_cast<uint32_t *>(dyn_smem + sizeof(Key<W>) * TILE);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t tile = blockIdx.x;
+    const uint64_t base = tile * TILE;
+    const uint32_t tile_n = (uint32_t)((n - base < (uint64_t)TILE) ? (n - base) : (uint64_t)TILE);
+
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) wave_cnt[w][tid] = 0;
+    __syncthreads();
+
+    Key<W> keys[ITEMS];
+    uint32_t vals[ITEMS];
+    uint32_t dig[ITEMS];
+    uint32_t rank[ITEMS];
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t local = (uint32_t)(wave * (ITEMS * 64) + i * 64 + lane);
+        const bool valid = local < tile_n;
+        uint32_t d = 0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) keys[i].w[j] = 0;
+        vals[i] = 0;
+        if (valid) {
+            keys[i] = key_load<W>(&in[base + local]);
+            if (HAS_VAL) vals[i] = vin[base + local];
+            d = digit_of<W>(keys[i], &in[base + local], pd);
+        }
+        dig[i] = d;
+        const uint64_t peers = match_digit(d, valid);
+        const uint32_t pre = wave_cnt[wave][d];
+        rank[i] = pre + (uint32_t)__popcll(peers & lt_mask);
+        // the highest lane of each peer group publishes the new running count
+        if (valid && (peers >> lane) == 1ull) wave_cnt[wave][d] = pre + (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+
+    // digit tid: exclusive prefix over waves, then exclusive scan over digits
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        uint32_t c = wave_cnt[w][tid];
+        wave_cnt[w][tid] = tot;
+        tot += c;
+    }
+    uint32_t tile_total;
+    const uint32_t dstart = block_excl_scan(tot, scan_tmp, &tile_total);
+    digit_start[tid] = dstart;
+    goff[tid] = tile_off[tile * kRadix + tid] - dstart;  // wraps mod 2^32; added back below
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t local = (uint32_t)(wave * (ITEMS * 64) + i * 64 + lane);
+        if (local < tile_n) {
+            const uint32_t pos = digit_start[dig[i]] + wave_cnt[wave][dig[i]] + rank[i];
+            key_store<W>(&stage[pos], keys[i]);
+            if (HAS_VAL) vstage[pos] = vals[i];
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t pos = (uint32_t)(i * kThreads + tid);
+        if (pos < tile_n) {
+            const Key<W> key = key_load<W>(&stage[pos]);
+            const uint32_t d = digit_of<W>(key, &stage[pos], pd);
+            const uint32_t g = goff[d] + pos;
+            key_store<W>(&out[g], key);
+            if (HAS_VAL) vout[g] = vstage[pos];
+        }
+    }
+}
+
+std::vector<PassDesc> key_passes(unsigned k) {
+    // least significant first: last word (populated low bits only) ... word 0
+    std::vector<PassDesc> p;
+    const int W = (int)words_of(k);
+    for (int w = W - 1; w >= 0; --w) {
+        const int bits = (w == W - 1) ? (int)(2 * k - 64 * (W - 1)) : 64;
+        for (int s = 0; s < bits; s += 8) {
+            const int b = (bits - s < 8) ? bits - s : 8;
+            p.push_back({0, w, s, b, 0});
+        }
+    }
+    return p;
+}
+
+template <int W>
+static void sort_impl(bbk_ctx *ctx, Key<W> *keys, Key<W> *tmp, uint32_t *vals, uint32_t *vtmp, uint64_t n,
+                      const std::vector<PassDesc> &passes) {
+    if (n <= 1 || passes.empty()) return;
+    BBK_REQUIRE(n < (1ull << 32), BBK_ERR_ARG, "sort_records: n=%llu does not fit 32-bit offsets (batch the input)",
+                (unsigned long long)n);
+    constexpr int TILE = SortCfg<W>::TILE;
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    const uint64_t nchunks = (ntiles + kChunk - 1) / kChunk;
+    DevBuf hist(ntiles * kRadix * sizeof(uint32_t));
+    DevBuf chunk(nchunks * kRadix * sizeof(uint64_t));
+    const size_t dyn = sizeof(Key<W>) * TILE + (vals ? sizeof(uint32_t) * TILE : 0);
+    if (vals) {
+        BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter<W, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    } else {
+        BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter<W, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    }
+    Key<W> *src = keys, *dst = tmp;
+    uint32_t *vsrc = vals, *vdst = vtmp;
+    const double rec_bytes = (double)(sizeof(Key<W>) + (vals ? 4 : 0));
+    for (const PassDesc &pd : passes) {
+        {
+            KernelTimer t(ctx, "hist", (double)n * sizeof(Key<W>));
+            hipLaunchKernelGGL(k_hist<W>, dim3((unsigned)ntiles), dim3(kThreads), 0, ctx->stream, src, n, pd,
+                               hist.as<uint32_t>());
+            check_launch("k_hist");
+        }
+        {
+            KernelTimer t(ctx, "scan", (double)ntiles * kRadix * 4 * 3);
+            hipLaunchKernelGGL(k_colsum, dim3((unsigned)nchunks), dim3(kRadix), 0, ctx->stream, hist.as<uint32_t>(),
+                               ntiles, chunk.as<uint64_t>());
+            hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kRadix), 0, ctx->stream, chunk.as<uint64_t>(), nchunks,
+                               (uint64_t *)nullptr);
+            hipLaunchKernelGGL(k_tile_offsets, dim3((unsigned)nchunks), dim3(kRadix), 0, ctx->stream,
+                               hist.as<uint32_t>(), ntiles, chunk.as<uint64_t>());
+            check_launch("scan kernels");
+        }
+        {
+            KernelTimer t(ctx, "scatter", 2.0 * (double)n * rec_bytes);
+            if (vals) {
+                hipLaunchKernelGGL((k_scatter<W, true>), dim3((unsigned)ntiles), dim3(kThreads), dyn, ctx->stream, src,
+                                   dst, vsrc, vdst, n, pd, hist.as<uint32_t>());
+            } else {
+                hipLaunchKernelGGL((k_scatter<W, false>), dim3((unsigned)ntiles), dim3(kThreads), dyn, ctx->stream,
+                                   src, dst, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, pd,
+                                   hist.as<uint32_t>());
+            }
+            check_launch("k_scatter");
+        }
+        std::swap(src, dst);
+        std::swap(vsrc, vdst);
+    }
+    if (src != keys) {
+        BBK_HIP(hipMemcpyAsync(keys, src, n * sizeof(Key<W>), hipMemcpyDeviceToDevice, ctx->stream));
+        if (vals) BBK_HIP(hipMemcpyAsync(vals, vsrc, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    BBK_HIP(hipStreamSynchronize(ctx->stream));  // hist/chunk are freed on return
+}
+
+void sort_records(bbk_ctx *ctx, int W, void *keys, void *keys_tmp, uint32_t *vals, uint32_t *vals_tmp, uint64_t n,
+                  const std::vector<PassDesc> &passes) {
+    switch (W) {
+        case 1: sort_impl<1>(ctx, (Key<1> *)keys, (Key<1> *)keys_tmp, vals, vals_tmp, n, passes); break;
+        case 2: sort_impl<2>(ctx, (Key<2> *)keys, (Key<2> *)keys_tmp, vals, vals_tmp, n, passes); break;
+        case 3: sort_impl<3>(ctx, (Key<3> *)keys, (Key<3> *)keys_tmp, vals, vals_tmp, n, passes); break;
+        case 4: sort_impl<4>(ctx, (Key<4> *)keys, (Key<4> *)keys_tmp, vals, vals_tmp, n, passes); break;
+        default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %d", W);
+    }
+}
+
+template <int W>
+static void digit_hist_impl(bbk_ctx *ctx, const Key<W> *keys, uint64_t n, PassDesc pd, uint64_t *h_counts) {
+    memset(h_counts, 0, kRadix * sizeof(uint64_t));
+    if (n == 0) return;
+    constexpr int TILE = SortCfg<W>::TILE;
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    const uint64_t nchunks = (ntiles + kChunk - 1) / kChunk;
+    DevBuf hist(ntiles * kRadix * sizeof(uint32_t));
+    DevBuf chunk(nchunks * kRadix * sizeof(uint64_t));
+    DevBuf tot(kRadix * sizeof(uint64_t));
+    hipLaunchKernelGGL(k_hist<W>, dim3((unsigned)ntiles), dim3(kThreads), 0, ctx->stream, keys, n, pd,
+                       hist.as<uint32_t>());
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)nchunks), dim3(kRadix), 0, ctx->stream, hist.as<uint32_t>(), ntiles,
+                       chunk.as<uint64_t>());
+    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kRadix), 0, ctx->stream, chunk.as<uint64_t>(), nchunks,
+                       tot.as<uint64_t>());
+    check_launch("digit_histogram");
+    BBK_HIP(hipMemcpyAsync(h_counts, tot.p, kRadix * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    BBK_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+void digit_histogram(bbk_ctx *ctx, int W, const void *keys, uint64_t n, PassDesc pd, uint64_t *h_counts) {
+    switch (W) {
+        case 1: digit_hist_impl<1>(ctx, (const Key<1> *)keys, n, pd, h_counts); break;
+        case 2: digit_hist_impl<2>(ctx, (const Key<2> *)keys, n, pd, h_counts); break;
+        case 3: digit_hist_impl<3>(ctx, (const Key<3> *)keys, n, pd, h_counts); break;
+        case 4: digit_hist_impl<4>(ctx, (const Key<4> *)keys, n, pd, h_counts); break;
+        default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %d", W);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// unique / reduce-by-key on a sorted array
+// ------------------------------------------------------------------------------------------
+constexpr int kUniqItems = 8;
+constexpr int kUniqTile = kThreads * kUniqItems;
+
+template <int W>
+__device__ inline bool is_head(const Key<W> *__restrict__ keys, uint64_t idx) {
+    if (idx == 0) return true;
+    return !key_eq<W>(keys[idx], keys[idx - 1]);
+}
+
+template <int W>
+__global__ __launch_bounds__(kThreads) void k_head_count(const Key<W> *__restrict__ keys, uint64_t n,
+                                                        uint64_t *__restrict__ bcount) {
+    __shared__ uint32_t sm[kWaves];
+    const uint64_t base = (uint64_t)blockIdx.x * kUniqTile;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < kUniqItems; ++i) {
+        uint64_t idx = base + (uint64_t)i * kThreads + threadIdx.x;
+        if (idx < n && is_head<W>(keys, idx)) ++c;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kWaves; ++w) t += sm[w];
+        bcount[blockIdx.x] = t;
+    }
+}
+
+// writes distinct keys and the index of each run head (head_idx has ndistinct+1 entries; the
+// last one, = n, is written by the host wrapper)
+template <int W>
+__global__ __launch_bounds__(kThreads) void k_head_compact(const Key<W> *__restrict__ keys, uint64_t n,
+                                                          const uint64_t *__restrict__ boff,
+                                                          Key<W> *__restrict__ out_keys,
+                                                          uint32_t *__restrict__ head_idx) {
+    __shared__ uint32_t scan_tmp[kWaves + 1];
+    const uint64_t base = (uint64_t)blockIdx.x * kUniqTile + (uint64_t)threadIdx.x * kUniqItems;
+    bool h[kUniqItems];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < kUniqItems; ++i) {
+        h[i] = (base + i < n) && is_head<W>(keys, base + i);
+        c += h[i] ? 1u : 0u;
+    }
+    uint32_t tot;
+    uint32_t pre = block_excl_scan(c, scan_tmp, &tot);
+    uint64_t pos = boff[blockIdx.x] + pre;
+#pragma unroll
+    for (int i = 0; i < kUniqItems; ++i) {
+        if (h[i]) {
+            if (out_keys) out_keys[pos] = keys[base + i];
+            head_idx[pos] = (uint32_t)(base + i);
+            ++pos;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_seg_reduce(const uint32_t *__restrict__ head_idx, uint64_t nseg,
+                                                        const uint32_t *__restrict__ vals, int op,
+                                                        uint32_t *__restrict__ out_vals) {
+    const uint64_t s = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (s >= nseg) return;
+    const uint32_t a = head_idx[s], b = head_idx[s + 1];
+    uint32_t r;
+    if (op == REDUCE_COUNT) {
+        r = b - a;
+    } else if (op == REDUCE_SUM) {
+        uint64_t t = 0;
+        for (uint32_t i = a; i < b; ++i) t += vals[i];
+        r = t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
+    } else {
+        r = 0;
+        for (uint32_t i = a; i < b; ++i) r |= vals[i];
+    }
+    out_vals[s] = r;
+}
+
+// compaction of (key, val) pairs with val != 0
+template <int W>
+__global__ __launch_bounds__(kThreads) void k_nonzero_count(const uint32_t *__restrict__ vals, uint64_t n,
+                                                           uint64_t *__restrict__ bcount) {
+    __shared__ uint32_t sm[kWaves];
+    const uint64_t base = (uint64_t)blockIdx.x * kUniqTile;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < kUniqItems; ++i) {
+        uint64_t idx = base + (uint64_t)i * kThreads + threadIdx.x;
+        if (idx < n && vals[idx] != 0) ++c;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kWaves; ++w) t += sm[w];
+        bcount[blockIdx.x] = t;
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(kThreads) void k_nonzero_compact(const Key<W> *__restrict__ keys,
+                                                             const uint32_t *__restrict__ vals, uint64_t n,
+                                                             const uint64_t *__restrict__ boff,
+                                                             Key<W> *__restrict__ out_keys,
+                                                             uint32_t *__restrict__ out_vals) {
+    __shared__ uint32_t scan_tmp[kWaves + 1];
+    const uint64_t base = (uint64_t)blockIdx.x * kUniqTile + (uint64_t)threadIdx.x * kUniqItems;
+    bool h[kUniqItems];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < kUniqItems; ++i) {
+        h[i] = (base + i < n) && vals[base + i] != 0;
+        c += h[i] ? 1u : 0u;
+    }
+    uint32_t tot;
+    uint32_t pre = block_excl_scan(c, scan_tmp, &tot);
+    uint64_t pos = boff[blockIdx.x] + pre;
+#pragma unroll
+    for (int i = 0; i < kUniqItems; ++i) {
+        if (h[i]) {
+            out_keys[pos] = keys[base + i];
+            out_vals[pos] = vals[base + i];
+            ++pos;
+        }
+    }
+}
+
+template <int W>
+static uint64_t unique_impl(bbk_ctx *ctx, const Key<W> *keys, const uint32_t *vals, uint64_t n, Key<W> *out_keys,
+                            uint32_t *out_vals, ReduceOp op, bool drop_zero) {
+    if (n == 0) return 0;
+    BBK_REQUIRE(n < (1ull << 32), BBK_ERR_ARG, "unique_records: n=%llu does not fit 32-bit offsets",
+                (unsigned long long)n);
+    const uint64_t nb = (n + kUniqTile - 1) / kUniqTile;
+    DevBuf bcount(nb * sizeof(uint64_t));
+    {
+        KernelTimer t(ctx, "unique", (double)n * sizeof(Key<W>));
+        hipLaunchKernelGGL(k_head_count<W>, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream, keys, n,
+                           bcount.as<uint64_t>());
+        check_launch("k_head_count");
+    }
+    const uint64_t nd = exclusive_scan_u64(ctx, bcount.as<uint64_t>(), bcount.as<uint64_t>(), nb);
+    DevBuf head((nd + 1) * sizeof(uint32_t));
+    const bool need_tmp = drop_zero && op == REDUCE_OR;
+    DevBuf tkeys, tvals;
+    Key<W> *dk = out_keys;
+    uint32_t *dv = out_vals;
+    if (need_tmp) {
+        tkeys.alloc(nd * sizeof(Key<W>));
+        tvals.alloc(nd * sizeof(uint32_t));
+        dk = tkeys.as<Key<W>>();
+        dv = tvals.as<uint32_t>();
+    }
+    {
+        KernelTimer t(ctx, "unique", (double)n * sizeof(Key<W>) + (double)nd * sizeof(Key<W>));
+        hipLaunchKernelGGL(k_head_compact<W>, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream, keys, n,
+                           bcount.as<uint64_t>(), dk, head.as<uint32_t>());
+        check_launch("k_head_compact");
+    }
+    const uint32_t n32 = (uint32_t)n;
+    BBK_HIP(hipMemcpyAsync(head.as<uint32_t>() + nd, &n32, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (dv) {
+        KernelTimer t(ctx, "reduce", (double)nd * 8 + (vals ? (double)n * 4 : 0));
+        hipLaunchKernelGGL(k_seg_reduce, dim3((unsigned)((nd + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                           ctx->stream, head.as<uint32_t>(), nd, vals, (int)op, dv);
+        check_launch("k_seg_reduce");
+    }
+    uint64_t result = nd;
+    if (need_tmp) {
+        const uint64_t nb2 = (nd + kUniqTile - 1) / kUniqTile;
+        DevBuf bc2(nb2 * sizeof(uint64_t));
+        hipLaunchKernelGGL(k_nonzero_count<W>, dim3((unsigned)nb2), dim3(kThreads), 0, ctx->stream, dv, nd,
+                           bc2.as<uint64_t>());
+        check_launch("k_nonzero_count");
+        result = exclusive_scan_u64(ctx, bc2.as<uint64_t>(), bc2.as<uint64_t>(), nb2);
+        hipLaunchKernelGGL(k_nonzero_compact<W>, dim3((unsigned)nb2), dim3(kThreads), 0, ctx->stream, dk, dv, nd,
+                           bc2.as<uint64_t>(), out_keys, out_vals);
+        check_launch("k_nonzero_compact");
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    BBK_HIP(hipStreamSynchronize(ctx->stream));
+    return result;
+}
+
+uint64_t unique_records(bbk_ctx *ctx, int W, const void *keys, const uint32_t *vals, uint64_t n, void *out_keys,
+                        uint32_t *out_vals, ReduceOp op, bool drop_zero) {
+    switch (W) {
+        case 1: return unique_impl<1>(ctx, (const Key<1> *)keys, vals, n, (Key<1> *)out_keys, out_vals, op, drop_zero);
+        case 2: return unique_impl<2>(ctx, (const Key<2> *)keys, vals, n, (Key<2> *)out_keys, out_vals, op, drop_zero);
+        case 3: return unique_impl<3>(ctx, (const Key<3> *)keys, vals, n, (Key<3> *)out_keys, out_vals, op, drop_zero);
+        case 4: return unique_impl<4>(ctx, (const Key<4> *)keys, vals, n, (Key<4> *)out_keys, out_vals, op, drop_zero);
+        default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %d", W);
+    }
+    return 0;
+}
+
+}  // namespace bbk
+
+// ---- context (C ABI) -------------------------------------------------------------------------
+void bbk_ctx::resolve_pending() {
+    for (auto &p : pending) {
+        (void)hipEventSynchronize(p.b);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto &s = stats[p.family];
+            s.ms += ms;
+            s.launches += 1;
+            s.bytes += p.bytes;
+        }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    pending.clear();
+}
+
+namespace bbk {
+const char *get_error();
+}
+
+extern "C" {
+
+const char *bbk_last_error(void) { return bbk::get_error(); }
+const char *bbk_version(void) { return "bbk 0.1 (gfx950)"; }
+
+int bbk_ctx_create(int device, bbk_ctx **out) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(out != nullptr, BBK_ERR_ARG, "bbk_ctx_create: out is NULL");
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        BBK_REQUIRE(e == hipSuccess && ndev > 0, BBK_ERR_HIP,
+                    "bbk_ctx_create: no HIP device available (%s); this engine has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        BBK_REQUIRE(device >= 0 && device < ndev, BBK_ERR_ARG, "bbk_ctx_create: device %d out of range [0,%d)", device,
+                    ndev);
+        BBK_HIP(hipSetDevice(device));
+        bbk_ctx *c = new bbk_ctx();
+        c->device = device;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+        BBK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+        *out = c;
+    });
+}
+
+int bbk_ctx_destroy(bbk_ctx *ctx) {
+    if (!ctx) return BBK_OK;
+    (void)hipSetDevice(ctx->device);
+    ctx->resolve_pending();
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return BBK_OK;
+}
+
+int bbk_ctx_set_stream(bbk_ctx *ctx, void *hip_stream) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx != nullptr, BBK_ERR_ARG, "bbk_ctx_set_stream: ctx is NULL");
+        if (ctx->own_stream && ctx->stream) {
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+            BBK_HIP(hipStreamDestroy(ctx->stream));
+        }
+        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+        ctx->own_stream = false;
+    });
+}
+
+int bbk_ctx_synchronize(bbk_ctx *ctx) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx != nullptr, BBK_ERR_ARG, "bbk_ctx_synchronize: ctx is NULL");
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int bbk_ctx_profile_enable(bbk_ctx *ctx, int on) {
+    if (!ctx) return BBK_ERR_ARG;
+    ctx->profiling = on != 0;
+    return BBK_OK;
+}
+
+int bbk_ctx_profile_reset(bbk_ctx *ctx) {
+    if (!ctx) return BBK_ERR_ARG;
+    ctx->resolve_pending();
+    ctx->stats.clear();
+    return BBK_OK;
+}
+
+int bbk_ctx_profile_get(bbk_ctx *ctx, const char *family, double *ms_total, uint64_t *launches, double *bytes_total) {
+    if (!ctx || !family) return BBK_ERR_ARG;
+    ctx->resolve_pending();
+    auto it = ctx->stats.find(family);
+    bbk::FamilyStat s;
+    if (it != ctx->stats.end()) s = it->second;
+    if (ms_total) *ms_total = s.ms;
+    if (launches) *launches = s.launches;
+    if (bytes_total) *bytes_total = s.bytes;
+    return BBK_OK;
+}
+
+unsigned bbk_words(unsigned k) { return bbk::words_of(k); }
+
+}  // extern "C"

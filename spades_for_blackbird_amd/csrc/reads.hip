@@ -1,0 +1,275 @@
+// reads.hip -- the input side of the path: ASCII reads -> LongestValid run -> 2-bit packed words
+// in HBM (replaces io::EasyStream + LongestValidWrap, reference common/io/reads/io_helper.cpp:19-32,
+// longest_valid_wrapper.hpp:15-52; reverse complements are never materialised, kernels
+// canonicalise instead of RCWrap, rc_reader_wrapper.hpp:33-42), plus the on-device synthetic
+// read generator of SURVEY.md 8(d) used by bench.py.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "bbk_internal.h"
+#include "kmer_ops.h"
+
+namespace bbk {
+
+static inline bool is_nucl(char c) {  // reference common/sequence/nucl.hpp:45-62
+    switch (c) {
+        case 'A': case 'C': case 'G': case 'T':
+        case 'a': case 'c': case 'g': case 't':
+            return true;
+        default:
+            return false;
+    }
+}
+
+static inline uint64_t dignucl(char c) {  // nucl.hpp:120-130
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        default: return 3;
+    }
+}
+
+// longest maximal run of valid bases, first wins on ties (longest_valid_wrapper.hpp:15-41)
+static inline void longest_valid(const char *s, uint64_t len, uint64_t *from, uint64_t *to) {
+    uint64_t best_len = 0, best_pos = 0, pos = 0;
+    bool in = false;
+    for (uint64_t i = 0; i <= len; ++i) {
+        if (i < len && is_nucl(s[i])) {
+            if (!in) {
+                in = true;
+                pos = i;
+            }
+        } else if (in) {
+            if (i - pos > best_len) {
+                best_len = i - pos;
+                best_pos = pos;
+            }
+            in = false;
+        }
+    }
+    *from = best_pos;
+    *to = best_pos + best_len;
+}
+
+__device__ __host__ inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// genome base g: 2 bits of splitmix64(seed_genome + g/32)
+__device__ inline uint32_t genome_base(uint64_t seed, uint64_t g) {
+    return (uint32_t)((splitmix64(seed + (g >> 5)) >> ((g & 31) << 1)) & 3ull);
+}
+
+// one thread per (read, 32-base word)
+__global__ void k_synth_reads(uint64_t n_reads, uint32_t read_len, uint32_t words_per_read, uint64_t genome_len,
+                              uint32_t sub_thresh, uint64_t seed_genome, uint64_t seed_reads,
+                              uint64_t *__restrict__ words, uint64_t *__restrict__ woff, uint32_t *__restrict__ len) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = gid / words_per_read;
+    const uint32_t wj = (uint32_t)(gid % words_per_read);
+    if (r >= n_reads) return;
+    const uint64_t h = splitmix64(seed_reads ^ (r * 0xD1B54A32D192ED03ull));
+    const uint64_t start = (uint64_t)__umul64hi(splitmix64(h), genome_len - read_len + 1);
+    const bool flip = (h >> 63) != 0;
+    uint64_t w = 0;
+    for (uint32_t j = 0; j < 32; ++j) {
+        const uint32_t p = wj * 32 + j;  // position in the emitted read
+        if (p >= read_len) break;
+        const uint32_t q = flip ? (read_len - 1 - p) : p;  // position in the forward template
+        uint32_t b = genome_base(seed_genome, start + q);
+        const uint64_t e = splitmix64(h + 0x632BE59BD9B4E019ull * (q + 1));
+        if ((uint32_t)(e >> 32) < sub_thresh) b = (b + 1 + (uint32_t)(e % 3)) & 3u;
+        if (flip) b = 3 - b;
+        w |= (uint64_t)b << (j << 1);
+    }
+    words[r * words_per_read + wj] = w;
+    if (wj == 0) {
+        woff[r] = r * words_per_read;
+        len[r] = read_len;
+        if (r == n_reads - 1) woff[n_reads] = n_reads * words_per_read;
+    }
+}
+
+__global__ void k_len_to_u64(const uint32_t *__restrict__ len, uint64_t n, uint64_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = len[i];
+}
+
+__global__ void k_unpack_ascii(const uint64_t *__restrict__ words, const uint64_t *__restrict__ woff,
+                               const uint32_t *__restrict__ len, const uint64_t *__restrict__ boff, uint64_t n_reads,
+                               char *__restrict__ out) {
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (r >= n_reads) return;
+    const int lane = threadIdx.x & 63;
+    const uint64_t *rw = words + woff[r];
+    const uint32_t L = len[r];
+    const uint64_t o = boff[r];
+    for (uint32_t p = lane; p < L; p += 64) out[o + p] = "ACGT"[base_at(rw, p)];
+}
+
+}  // namespace bbk
+
+extern "C" {
+
+int bbk_reads_from_ascii(bbk_ctx *ctx, const char *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+                         bbk_reads **out) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx && out && (n_reads == 0 || (h_bases && h_offsets)), BBK_ERR_ARG,
+                    "bbk_reads_from_ascii: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        std::vector<uint64_t> woff(n_reads + 1);
+        std::vector<uint32_t> len(n_reads);
+        std::vector<uint64_t> from(n_reads);
+        uint64_t nw = 0, bases = 0;
+        for (uint64_t r = 0; r < n_reads; ++r) {
+            uint64_t f, t;
+            bbk::longest_valid(h_bases + h_offsets[r], h_offsets[r + 1] - h_offsets[r], &f, &t);
+            BBK_REQUIRE(t - f < (1ull << 32), BBK_ERR_ARG, "read %llu longer than 2^32 bases", (unsigned long long)r);
+            from[r] = h_offsets[r] + f;
+            len[r] = (uint32_t)(t - f);
+            woff[r] = nw;
+            nw += (len[r] + 31) / 32;
+            bases += len[r];
+        }
+        woff[n_reads] = nw;
+        std::vector<uint64_t> words(nw + 1, 0);
+#pragma omp parallel for schedule(static)
+        for (uint64_t r = 0; r < n_reads; ++r) {
+            const char *s = h_bases + from[r];
+            uint64_t *w = words.data() + woff[r];
+            for (uint32_t i = 0; i < len[r]; ++i) w[i >> 5] |= bbk::dignucl(s[i]) << ((i & 31) << 1);
+        }
+        auto rd = new bbk_reads();
+        std::unique_ptr<bbk_reads> guard(rd);
+        rd->ctx = ctx;
+        rd->n = n_reads;
+        rd->n_words = nw;
+        rd->bases = bases;
+        rd->own_words.alloc((nw + 1) * sizeof(uint64_t));
+        rd->own_woff.alloc((n_reads + 1) * sizeof(uint64_t));
+        rd->own_len.alloc((n_reads + 1) * sizeof(uint32_t));
+        BBK_HIP(hipMemcpyAsync(rd->own_words.p, words.data(), (nw + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
+                               ctx->stream));
+        BBK_HIP(hipMemcpyAsync(rd->own_woff.p, woff.data(), (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
+                               ctx->stream));
+        if (n_reads)
+            BBK_HIP(hipMemcpyAsync(rd->own_len.p, len.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                   ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        rd->d_words = rd->own_words.as<uint64_t>();
+        rd->d_woff = rd->own_woff.as<uint64_t>();
+        rd->d_len = rd->own_len.as<uint32_t>();
+        *out = guard.release();
+    });
+}
+
+int bbk_reads_from_device(bbk_ctx *ctx, const void *d_words, const void *d_word_off, const void *d_len,
+                          uint64_t n_reads, uint64_t n_words, bbk_reads **out) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx && out && d_words && d_word_off && d_len, BBK_ERR_ARG, "bbk_reads_from_device: NULL argument");
+        auto rd = new bbk_reads();
+        rd->ctx = ctx;
+        rd->n = n_reads;
+        rd->n_words = n_words;
+        rd->d_words = (const uint64_t *)d_words;
+        rd->d_woff = (const uint64_t *)d_word_off;
+        rd->d_len = (const uint32_t *)d_len;
+        rd->bases = 0;  // unknown without a reduction; only informational
+        *out = rd;
+    });
+}
+
+int bbk_reads_synth(bbk_ctx *ctx, uint64_t n_reads, uint32_t read_len, uint64_t genome_len, double sub_rate,
+                    uint64_t seed_genome, uint64_t seed_reads, bbk_reads **out) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx && out, BBK_ERR_ARG, "bbk_reads_synth: NULL argument");
+        BBK_REQUIRE(read_len >= 1 && genome_len >= read_len && sub_rate >= 0 && sub_rate < 1, BBK_ERR_ARG,
+                    "bbk_reads_synth: bad shape (read_len=%u genome_len=%llu sub_rate=%g)", read_len,
+                    (unsigned long long)genome_len, sub_rate);
+        BBK_HIP(hipSetDevice(ctx->device));
+        const uint32_t wpr = (read_len + 31) / 32;
+        auto rd = new bbk_reads();
+        std::unique_ptr<bbk_reads> guard(rd);
+        rd->ctx = ctx;
+        rd->n = n_reads;
+        rd->n_words = n_reads * wpr;
+        rd->bases = n_reads * read_len;
+        rd->own_words.alloc((rd->n_words + 1) * sizeof(uint64_t));
+        rd->own_woff.alloc((n_reads + 1) * sizeof(uint64_t));
+        rd->own_len.alloc((n_reads + 1) * sizeof(uint32_t));
+        if (n_reads) {
+            const uint64_t total = n_reads * wpr;
+            const uint32_t thresh = (uint32_t)(sub_rate * 4294967296.0);
+            hipLaunchKernelGGL(bbk::k_synth_reads, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                               n_reads, read_len, wpr, genome_len, thresh, seed_genome, seed_reads,
+                               rd->own_words.as<uint64_t>(), rd->own_woff.as<uint64_t>(), rd->own_len.as<uint32_t>());
+            bbk::check_launch("k_synth_reads");
+        } else {
+            BBK_HIP(hipMemsetAsync(rd->own_woff.p, 0, sizeof(uint64_t), ctx->stream));
+        }
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        rd->d_words = rd->own_words.as<uint64_t>();
+        rd->d_woff = rd->own_woff.as<uint64_t>();
+        rd->d_len = rd->own_len.as<uint32_t>();
+        *out = guard.release();
+    });
+}
+
+uint64_t bbk_reads_count(const bbk_reads *r) { return r ? r->n : 0; }
+uint64_t bbk_reads_bases(const bbk_reads *r) { return r ? r->bases : 0; }
+
+int bbk_reads_get_ascii(bbk_ctx *ctx, const bbk_reads *r, uint64_t i, char *h_dst, uint32_t cap, uint32_t *len) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx && r && h_dst && len && i < r->n, BBK_ERR_ARG, "bbk_reads_get_ascii: bad argument");
+        uint64_t wo[2];
+        uint32_t L;
+        BBK_HIP(hipMemcpy(wo, r->d_woff + i, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        BBK_HIP(hipMemcpy(&L, r->d_len + i, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        BBK_REQUIRE(L + 1 <= cap, BBK_ERR_ARG, "bbk_reads_get_ascii: buffer too small (%u needed)", L + 1);
+        std::vector<uint64_t> w(wo[1] - wo[0] + 1);
+        if (wo[1] > wo[0])
+            BBK_HIP(hipMemcpy(w.data(), r->d_words + wo[0], (wo[1] - wo[0]) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (uint32_t p = 0; p < L; ++p) h_dst[p] = "ACGT"[(w[p >> 5] >> ((p & 31) << 1)) & 3];
+        h_dst[L] = 0;
+        *len = L;
+    });
+}
+
+int bbk_reads_export_ascii(bbk_ctx *ctx, const bbk_reads *r, char *h_bases, uint64_t *h_offsets, uint64_t cap_bases) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx && r && h_offsets, BBK_ERR_ARG, "bbk_reads_export_ascii: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        const uint64_t n = r->n;
+        h_offsets[0] = 0;
+        if (n == 0) return;
+        bbk::DevBuf boff((n + 1) * sizeof(uint64_t));
+        hipLaunchKernelGGL(bbk::k_len_to_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, r->d_len, n,
+                           boff.as<uint64_t>());
+        bbk::check_launch("k_len_to_u64");
+        const uint64_t total = bbk::exclusive_scan_u64(ctx, boff.as<uint64_t>(), boff.as<uint64_t>(), n);
+        BBK_HIP(hipMemcpyAsync(h_offsets, boff.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        h_offsets[n] = total;
+        if (h_bases) {
+            BBK_REQUIRE(total <= cap_bases, BBK_ERR_ARG, "bbk_reads_export_ascii: buffer too small (%llu needed)",
+                        (unsigned long long)total);
+            bbk::DevBuf out(total + 1);
+            hipLaunchKernelGGL(bbk::k_unpack_ascii, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, r->d_words,
+                               r->d_woff, r->d_len, boff.as<uint64_t>(), n, out.as<char>());
+            bbk::check_launch("k_unpack_ascii");
+            BBK_HIP(hipMemcpyAsync(h_bases, out.p, total, hipMemcpyDeviceToHost, ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+void bbk_reads_free(bbk_reads *r) { delete r; }
+
+}  // extern "C"

@@ -1,0 +1,361 @@
+"""ctypes binding of libbbk.so (include/bbk.h).  Fails loudly when the HIP library is missing."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+BOTH_STRANDS, CANONICAL, WITH_COUNTS = 1, 2, 4
+ORDER_SORTED, ORDER_REFERENCE_BUCKETS16 = 0, 1
+
+# every symbol include/bbk.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "bbk_last_error", "bbk_version", "bbk_ctx_create", "bbk_ctx_destroy", "bbk_ctx_set_stream",
+    "bbk_ctx_synchronize", "bbk_ctx_profile_enable", "bbk_ctx_profile_reset", "bbk_ctx_profile_get",
+    "bbk_reads_from_ascii", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_count", "bbk_reads_bases",
+    "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
+    "bbk_count", "bbk_kmerset_from_device", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k",
+    "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
+    "bbk_kmerset_write_final_kmers",
+    "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_free",
+    "bbk_unitigs_build", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
+    "bbk_unitigs_vertices", "bbk_unitigs_links", "bbk_unitigs_export", "bbk_unitigs_export_links",
+    "bbk_unitigs_write_gfa", "bbk_unitigs_write_fasta", "bbk_unitigs_free",
+]
+
+
+class BBKError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libbbk.so")
+
+
+def load_library():
+    """Loads libbbk.so; raises BBKError if it has not been built (no fallback exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise BBKError("libbbk.so is missing: build it with `python -m spades_for_blackbird_amd.build` "
+                       "(hipcc --offload-arch=gfx950); this engine has no CPU fallback")
+    L = C.CDLL(p)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    L.bbk_last_error.restype = C.c_char_p
+    L.bbk_version.restype = C.c_char_p
+    L.bbk_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.bbk_ctx_destroy.argtypes = [vp]
+    L.bbk_ctx_set_stream.argtypes = [vp, vp]
+    L.bbk_ctx_synchronize.argtypes = [vp]
+    L.bbk_ctx_profile_enable.argtypes = [vp, i32]
+    L.bbk_ctx_profile_reset.argtypes = [vp]
+    L.bbk_ctx_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(C.c_double)]
+    L.bbk_reads_from_ascii.argtypes = [vp, C.c_char_p, vp, u64, C.POINTER(vp)]
+    L.bbk_reads_from_device.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
+    L.bbk_reads_synth.argtypes = [vp, u64, u32, u64, C.c_double, u64, u64, C.POINTER(vp)]
+    L.bbk_reads_count.restype = u64
+    L.bbk_reads_count.argtypes = [vp]
+    L.bbk_reads_bases.restype = u64
+    L.bbk_reads_bases.argtypes = [vp]
+    L.bbk_reads_get_ascii.argtypes = [vp, vp, u64, C.c_char_p, u32, C.POINTER(u32)]
+    L.bbk_reads_export_ascii.argtypes = [vp, vp, vp, vp, u64]
+    L.bbk_reads_free.argtypes = [vp]
+    L.bbk_count.argtypes = [vp, vp, C.c_uint, C.c_uint, C.POINTER(vp)]
+    L.bbk_kmerset_from_device.argtypes = [vp, vp, vp, u64, C.c_uint, C.POINTER(vp)]
+    L.bbk_words.restype = C.c_uint
+    L.bbk_words.argtypes = [C.c_uint]
+    L.bbk_kmerset_size.restype = u64
+    L.bbk_kmerset_size.argtypes = [vp]
+    L.bbk_kmerset_k.restype = C.c_uint
+    L.bbk_kmerset_k.argtypes = [vp]
+    L.bbk_kmerset_instances.restype = u64
+    L.bbk_kmerset_instances.argtypes = [vp]
+    L.bbk_kmerset_export.argtypes = [vp, vp, C.c_uint, vp, vp]
+    L.bbk_kmerset_export_by_owner.argtypes = [vp, vp, C.c_uint, vp, vp, vp]
+    L.bbk_kmerset_free.argtypes = [vp]
+    L.bbk_kmerset_write_final_kmers.argtypes = [vp, vp, C.c_char_p]
+    if hasattr(L, "bbk_extindex_build"):
+        L.bbk_extindex_build.argtypes = [vp, vp, C.c_uint, C.POINTER(vp)]
+        L.bbk_extindex_size.restype = u64
+        L.bbk_extindex_size.argtypes = [vp]
+        L.bbk_extindex_k.restype = C.c_uint
+        L.bbk_extindex_k.argtypes = [vp]
+        L.bbk_extindex_export.argtypes = [vp, vp, vp, vp]
+        L.bbk_extindex_free.argtypes = [vp]
+    if hasattr(L, "bbk_unitigs_build"):
+        L.bbk_unitigs_build.argtypes = [vp, vp, C.POINTER(vp)]
+        for f in ("count", "loops", "total_bases", "vertices", "links"):
+            getattr(L, "bbk_unitigs_" + f).restype = u64
+            getattr(L, "bbk_unitigs_" + f).argtypes = [vp]
+        L.bbk_unitigs_export.argtypes = [vp, vp, vp, vp]
+        L.bbk_unitigs_export_links.argtypes = [vp, vp, vp]
+        L.bbk_unitigs_write_gfa.argtypes = [vp, vp, C.c_char_p]
+        L.bbk_unitigs_write_fasta.argtypes = [vp, vp, C.c_char_p]
+        L.bbk_unitigs_free.argtypes = [vp]
+    _LIB = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise BBKError("bbk error %d: %s" % (rc, load_library().bbk_last_error().decode(errors="replace")))
+
+
+def _ptr(x):
+    """Host numpy array, torch tensor (host or device) or raw int -> void pointer."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if isinstance(x, np.ndarray):
+        return C.c_void_p(x.ctypes.data)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    raise TypeError("cannot take a pointer of %r" % type(x))
+
+
+def words(k):
+    return (k + 31) // 32
+
+
+class Context:
+    """One per GPU / process (bbk_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = load_library()
+        h = C.c_void_p()
+        _check(self._L.bbk_ctx_create(device, C.byref(h)))
+        self._h = h
+        self.device = device
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        """stream: raw hipStream_t as int, or a torch.cuda.Stream."""
+        raw = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+        _check(self._L.bbk_ctx_set_stream(self._h, C.c_void_p(raw)))
+
+    def synchronize(self):
+        _check(self._L.bbk_ctx_synchronize(self._h))
+
+    def profile(self, on=True):
+        _check(self._L.bbk_ctx_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        _check(self._L.bbk_ctx_profile_reset(self._h))
+
+    def profile_get(self, family):
+        ms, n, b = C.c_double(), C.c_uint64(), C.c_double()
+        _check(self._L.bbk_ctx_profile_get(self._h, family.encode(), C.byref(ms), C.byref(n), C.byref(b)))
+        return {"ms": ms.value, "launches": n.value, "bytes": b.value}
+
+    # ---- reads -------------------------------------------------------------------------------
+    def reads_from_ascii(self, reads):
+        bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+        offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+        if bs:
+            offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        return self.reads_from_blob(b"".join(bs), offs)
+
+    def reads_from_blob(self, blob, offsets):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(self._L.bbk_reads_from_ascii(self._h, blob, _ptr(offsets), len(offsets) - 1, C.byref(h)))
+        return Reads(self, h)
+
+    def reads_from_device(self, d_words, d_word_off, d_len, n_reads, n_words):
+        h = C.c_void_p()
+        _check(self._L.bbk_reads_from_device(self._h, _ptr(d_words), _ptr(d_word_off), _ptr(d_len), n_reads, n_words,
+                                             C.byref(h)))
+        r = Reads(self, h)
+        r._keep = (d_words, d_word_off, d_len)
+        return r
+
+    def reads_synth(self, n_reads, read_len=150, genome_len=None, sub_rate=0.005, seed_genome=42, seed_reads=43):
+        if genome_len is None:
+            genome_len = max(read_len, n_reads * read_len // 50)
+        h = C.c_void_p()
+        _check(self._L.bbk_reads_synth(self._h, n_reads, read_len, genome_len, sub_rate, seed_genome, seed_reads,
+                                       C.byref(h)))
+        return Reads(self, h)
+
+    # ---- operators -----------------------------------------------------------------------------
+    def count(self, reads, k, flags=BOTH_STRANDS):
+        """KMerCounter::Count analogue (reference kmer_index_builder.hpp:195-217)."""
+        h = C.c_void_p()
+        _check(self._L.bbk_count(self._h, reads._h, k, flags, C.byref(h)))
+        return KMerSet(self, h)
+
+    def kmerset_from_device(self, d_keys, n, k, d_counts=None):
+        h = C.c_void_p()
+        _check(self._L.bbk_kmerset_from_device(self._h, _ptr(d_keys), _ptr(d_counts), n, k, C.byref(h)))
+        return KMerSet(self, h)
+
+    def extindex(self, reads, k):
+        """DeBruijnExtensionIndexBuilder::BuildExtensionIndexFromStream analogue."""
+        h = C.c_void_p()
+        _check(self._L.bbk_extindex_build(self._h, reads._h, k, C.byref(h)))
+        return ExtIndex(self, h)
+
+    def unitigs(self, ext):
+        """UnbranchingPathExtractor + FastGraphFromSequencesConstructor analogue."""
+        h = C.c_void_p()
+        _check(self._L.bbk_unitigs_build(self._h, ext._h, C.byref(h)))
+        return Unitigs(self, h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.bbk_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Handle:
+    _free = None
+
+    def __init__(self, ctx, h):
+        self.ctx, self._h, self._L = ctx, h, ctx._L
+
+    def free(self):
+        if getattr(self, "_h", None):
+            getattr(self._L, self._free)(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Reads(_Handle):
+    _free = "bbk_reads_free"
+
+    def __len__(self):
+        return int(self._L.bbk_reads_count(self._h))
+
+    @property
+    def bases(self):
+        return int(self._L.bbk_reads_bases(self._h))
+
+    def to_ascii(self):
+        """(blob bytes, offsets np.uint64[n+1])"""
+        n = len(self)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        _check(self._L.bbk_reads_export_ascii(self.ctx._h, self._h, None, _ptr(offs), 0))
+        total = int(offs[n])
+        buf = np.zeros(total + 1, dtype=np.uint8)
+        _check(self._L.bbk_reads_export_ascii(self.ctx._h, self._h, _ptr(buf), _ptr(offs), total))
+        return buf[:total].tobytes(), offs
+
+    def to_list(self):
+        blob, offs = self.to_ascii()
+        return [blob[int(offs[i]):int(offs[i + 1])].decode() for i in range(len(offs) - 1)]
+
+
+class KMerSet(_Handle):
+    _free = "bbk_kmerset_free"
+
+    def __len__(self):
+        return int(self._L.bbk_kmerset_size(self._h))
+
+    @property
+    def k(self):
+        return int(self._L.bbk_kmerset_k(self._h))
+
+    @property
+    def instances(self):
+        return int(self._L.bbk_kmerset_instances(self._h))
+
+    def export(self, order=ORDER_SORTED, with_counts=False):
+        n, nw = len(self), words(self.k)
+        keys = np.zeros((n, nw), dtype=np.uint64)
+        cnt = np.zeros(n, dtype=np.uint32) if with_counts else None
+        _check(self._L.bbk_kmerset_export(self.ctx._h, self._h, order, _ptr(keys), _ptr(cnt)))
+        return (keys, cnt) if with_counts else keys
+
+    def export_to(self, dst_keys, order=ORDER_SORTED, dst_counts=None):
+        """dst_*: preallocated torch tensors (device or host) or numpy arrays."""
+        _check(self._L.bbk_kmerset_export(self.ctx._h, self._h, order, _ptr(dst_keys), _ptr(dst_counts)))
+
+    def export_by_owner(self, nranks, dst_keys=None, dst_counts=None):
+        n, nw = len(self), words(self.k)
+        counts = np.zeros(nranks, dtype=np.uint64)
+        ret = None
+        if dst_keys is None:
+            dst_keys = ret = np.zeros((n, nw), dtype=np.uint64)
+        _check(self._L.bbk_kmerset_export_by_owner(self.ctx._h, self._h, nranks, _ptr(dst_keys), _ptr(dst_counts),
+                                                   _ptr(counts)))
+        return (ret, counts) if ret is not None else counts
+
+    def write_final_kmers(self, path):
+        _check(self._L.bbk_kmerset_write_final_kmers(self.ctx._h, self._h, path.encode()))
+
+
+class ExtIndex(_Handle):
+    _free = "bbk_extindex_free"
+
+    def __len__(self):
+        return int(self._L.bbk_extindex_size(self._h))
+
+    @property
+    def k(self):
+        return int(self._L.bbk_extindex_k(self._h))
+
+    def export(self):
+        n, nw = len(self), words(self.k)
+        keys = np.zeros((n, nw), dtype=np.uint64)
+        masks = np.zeros(n, dtype=np.uint8)
+        _check(self._L.bbk_extindex_export(self.ctx._h, self._h, _ptr(keys), _ptr(masks)))
+        return keys, masks
+
+
+class Unitigs(_Handle):
+    _free = "bbk_unitigs_free"
+
+    def __len__(self):
+        return int(self._L.bbk_unitigs_count(self._h))
+
+    @property
+    def n_loops(self):
+        return int(self._L.bbk_unitigs_loops(self._h))
+
+    @property
+    def n_vertices(self):
+        return int(self._L.bbk_unitigs_vertices(self._h))
+
+    @property
+    def n_links(self):
+        return int(self._L.bbk_unitigs_links(self._h))
+
+    @property
+    def total_bases(self):
+        return int(self._L.bbk_unitigs_total_bases(self._h))
+
+    def sequences(self):
+        n = len(self)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        buf = np.zeros(self.total_bases + 1, dtype=np.uint8)
+        _check(self._L.bbk_unitigs_export(self.ctx._h, self._h, _ptr(buf), _ptr(offs)))
+        b = buf.tobytes()
+        return [b[int(offs[i]):int(offs[i + 1])].decode() for i in range(n)]
+
+    def links(self):
+        a = np.zeros((self.n_links, 4), dtype=np.uint32)
+        _check(self._L.bbk_unitigs_export_links(self.ctx._h, self._h, _ptr(a)))
+        return a
+
+    def write_gfa(self, path):
+        _check(self._L.bbk_unitigs_write_gfa(self.ctx._h, self._h, path.encode()))
+
+    def write_fasta(self, path):
+        _check(self._L.bbk_unitigs_write_fasta(self.ctx._h, self._h, path.encode()))

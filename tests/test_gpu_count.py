@@ -1,0 +1,145 @@
+"""GPU parity tests of the k-mer counting path (through the C ABI) against the CPU oracle and
+the reference's golden vectors.  Bit-exact: integer/byte work."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import spades_for_blackbird_amd as B
+from oracle import oracle as O
+from tests.helpers import rc, read_fastq_gz, synth_reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = B.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_final_kmers(ctx, reads, k, with_counts=False):
+    r = ctx.reads_from_ascii(reads)
+    s = ctx.count(r, k, B.BOTH_STRANDS | (B.WITH_COUNTS if with_counts else 0))
+    return s.export(B.ORDER_REFERENCE_BUCKETS16, with_counts=with_counts)
+
+
+def test_toy_md5(ctx, golden, golden_dir):
+    g = golden["toy_kmercount"]
+    reads = []
+    for f in g["files"]:
+        reads += read_fastq_gz(os.path.join(golden_dir, f))
+    for k, key in ((21, "k21"), (55, "k55")):
+        a = gpu_final_kmers(ctx, reads, k)
+        assert len(a) == g[key]["n_kmers"]
+        assert hashlib.md5(a.tobytes()).hexdigest() == g[key]["md5"]
+    a = gpu_final_kmers(ctx, read_fastq_gz(os.path.join(golden_dir, g["files"][0])), 77)
+    assert len(a) == g["k77"]["n_kmers_r1_only"]
+
+
+def test_write_final_kmers(ctx, golden, golden_dir, tmp_path):
+    g = golden["toy_kmercount"]
+    reads = []
+    for f in g["files"]:
+        reads += read_fastq_gz(os.path.join(golden_dir, f))
+    s = ctx.count(ctx.reads_from_ascii(reads), 21, B.BOTH_STRANDS)
+    p = str(tmp_path / "final_kmers")
+    s.write_final_kmers(p)
+    with open(p, "rb") as f:
+        assert hashlib.md5(f.read()).hexdigest() == g["k21"]["md5"]
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 5, 16, 21, 22, 31, 32, 33, 55, 63, 64, 65, 77, 96, 97, 127])
+def test_vs_oracle_all_k(ctx, k):
+    reads = synth_reads(400, read_len=150, genome_len=3000, sub_rate=0.01, seed=k, n_rate=0.002)
+    reads += ["", "A", "ACGT" * 40, "N" * 50, "acgtnACGTTGCA" * 12, "T" * 150]
+    exp, expc = O.kmercount(reads, k, 16, 2, with_counts=True)
+    got, gotc = gpu_final_kmers(ctx, reads, k, with_counts=True)
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp)
+    assert np.array_equal(gotc, expc)
+
+
+def test_sorted_order_and_canonical(ctx):
+    reads = synth_reads(2000, read_len=100, genome_len=20000, sub_rate=0.005, seed=11)
+    for k in (21, 33):
+        r = ctx.reads_from_ascii(reads)
+        s = ctx.count(r, k, B.CANONICAL | B.WITH_COUNTS)
+        keys, cnt = s.export(B.ORDER_SORTED, with_counts=True)
+        x = O.ExtIndex(reads, k - 1, 1)  # canonical k-mers = the (k-1)+1-mers of the ext index build
+        exp = x.kp1
+        order = np.lexsort([exp[:, j] for j in range(exp.shape[1] - 1, -1, -1)])
+        assert np.array_equal(keys, exp[order])
+        assert np.array_equal(cnt, x.kp1_count[order])
+        assert s.instances == sum(max(0, len(t) - k + 1) for t in reads)
+
+
+def test_empty_and_short(ctx):
+    for reads in ([], [""], ["ACG"], ["NNNN", "AC"]):
+        a = gpu_final_kmers(ctx, reads, 5)
+        assert a.shape == (0, 1)
+    a, c = gpu_final_kmers(ctx, ["ACGTA"], 5, with_counts=True)
+    exp, expc = O.kmercount(["ACGTA"], 5, 16, 1, with_counts=True)
+    assert np.array_equal(a, exp) and np.array_equal(c, expc)
+
+
+def test_palindromes_even_k(ctx):
+    reads = ["ACGTACGTACGT", "AATT", "GGCC" * 5]
+    for k in (2, 4, 6):
+        a, c = gpu_final_kmers(ctx, reads, k, with_counts=True)
+        exp, expc = O.kmercount(reads, k, 16, 1, with_counts=True)
+        assert np.array_equal(a, exp) and np.array_equal(c, expc)
+
+
+def test_synth_reads_roundtrip_and_parity(ctx):
+    r = ctx.reads_synth(3000, read_len=150, genome_len=9000, sub_rate=0.005, seed_genome=42, seed_reads=43)
+    reads = r.to_list()
+    assert len(reads) == 3000 and all(len(x) == 150 for x in reads)
+    r2 = ctx.reads_synth(3000, read_len=150, genome_len=9000, sub_rate=0.005, seed_genome=42, seed_reads=43)
+    assert r2.to_list() == reads  # deterministic
+    s = ctx.count(r, 21, B.BOTH_STRANDS)
+    a = s.export(B.ORDER_REFERENCE_BUCKETS16)
+    exp = O.kmercount(reads, 21, 16, 4)
+    assert np.array_equal(a, exp)
+    # coverage ~50x: far fewer distinct than instances
+    assert len(a) < s.instances // 4
+
+
+def test_larger_batch_properties(ctx):
+    """Size-independent properties at a size the oracle would take long for."""
+    r = ctx.reads_synth(400000, read_len=150, genome_len=1200000)
+    k = 21
+    s = ctx.count(r, k, B.BOTH_STRANDS | B.WITH_COUNTS)
+    keys, cnt = s.export(B.ORDER_SORTED, with_counts=True)
+    assert s.instances == 2 * 400000 * (150 - k + 1)
+    assert int(cnt.sum(dtype=np.uint64)) == s.instances          # multiplicities add up
+    assert np.all(keys[1:, 0] > keys[:-1, 0])                      # strictly ascending = distinct
+    ref = s.export(B.ORDER_REFERENCE_BUCKETS16)
+    assert np.array_equal(np.sort(ref[:, 0]), keys[:, 0])           # same multiset in both orders
+    # closed under reverse complement (spot check on a sample)
+    sample = keys[:: max(1, len(keys) // 2000), 0]
+    kset = set(int(x) for x in keys[:, 0])
+    for x in sample:
+        s_ = "".join("ACGT"[(int(x) >> (2 * i)) & 3] for i in range(k))
+        assert O.kmer_words(rc(s_))[0] in kset
+    # bucket ids ascend along the reference order
+    b = [O.bucket(row, 16) for row in ref[:: max(1, len(ref) // 5000)]]
+    assert b == sorted(b)
+
+
+def test_owner_partition(ctx):
+    reads = synth_reads(500, read_len=100, genome_len=5000, seed=3)
+    s = ctx.count(ctx.reads_from_ascii(reads), 21, B.CANONICAL)
+    keys = s.export(B.ORDER_SORTED)
+    for nranks in (1, 2, 8):
+        part, counts = s.export_by_owner(nranks)
+        assert int(counts.sum()) == len(keys)
+        assert np.array_equal(np.sort(part[:, 0]), keys[:, 0])
+        # owner segments are disjoint sets whose union is everything; each sorted inside
+        off = 0
+        for c in counts:
+            seg = part[off:off + int(c), 0]
+            assert np.all(seg[1:] > seg[:-1])
+            off += int(c)
