@@ -95,6 +95,9 @@ int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, 
  * optional u32 multiplicities that are summed).  Used after the multi-GPU exchange. */
 int bbk_kmerset_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, unsigned k,
                             bbk_kmerset **out);
+/* canon U rc(canon): the both-strand set of spades-kmercount from a BBK_CANONICAL set (each rank
+ * applies it to its own shard after the multi-GPU exchange). */
+int bbk_kmerset_both_strands(bbk_ctx *ctx, const bbk_kmerset *canon, bbk_kmerset **out);
 unsigned bbk_words(unsigned k); /* RtSeq::GetDataSize (common/sequence/rtseq.hpp:129-131) */
 uint64_t bbk_kmerset_size(const bbk_kmerset *s);
 unsigned bbk_kmerset_k(const bbk_kmerset *s);

@@ -57,6 +57,10 @@ int guarded(F &&f) {
     }
 }
 
+void *pool_alloc(size_t bytes, size_t *granted);
+void pool_free(void *p, size_t bytes);
+void pool_trim();  // hipFree everything cached
+
 // Owning device buffer.
 struct DevBuf {
     void *p = nullptr;
@@ -80,19 +84,19 @@ struct DevBuf {
         return *this;
     }
     ~DevBuf() { release(); }
+    // Device memory comes from a per-process caching pool (primitives.hip): hipMalloc/hipFree of
+    // multi-GB buffers cost far more than the kernels that use them, and every step of the path
+    // asks for the same sizes again.  All work of a context is issued on one stream, so handing a
+    // released block to the next request is stream-ordered and needs no synchronisation.
     void alloc(size_t n) {
         release();
         if (n == 0) n = 16;
-        hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) {
-            p = nullptr;
-            set_error("hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
-            throw Error{e == hipErrorOutOfMemory ? BBK_ERR_NOMEM : BBK_ERR_HIP};
-        }
-        bytes = n;
+        size_t got = 0;
+        p = pool_alloc(n, &got);
+        bytes = got;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p, bytes);
         p = nullptr;
         bytes = 0;
     }

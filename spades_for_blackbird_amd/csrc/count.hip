@@ -174,6 +174,44 @@ void count_canonical(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_ma
     n_distinct = D;
 }
 
+// canon U rc(canon): expand, sort, unique.  A k-mer equal to its own RC (even k) appears twice
+// and is merged by unique; its count doubles, as in the reference where both strands of such an
+// occurrence are counted.
+static void expand_both_strands(bbk_ctx *ctx, unsigned k, const DevBuf &ck, const DevBuf *cv, uint64_t D,
+                                bbk_kmerset &s) {
+    const bool wc = cv != nullptr;
+    const int W = (int)words_of(k);
+    const size_t rec = (size_t)W * 8;
+    if (D == 0) {
+        s.n = 0;
+        s.keys.alloc(16);
+        if (wc) s.counts.alloc(16);
+        return;
+    }
+    BBK_REQUIRE(2 * D < (1ull << 32), BBK_ERR_ARG, "too many distinct k-mers for one device batch");
+    DevBuf e(2 * D * rec), et(2 * D * rec), ec, ect;
+    if (wc) {
+        ec.alloc(2 * D * 4);
+        ect.alloc(2 * D * 4);
+    }
+    BBK_DISPATCH_W(W, launch_expand<W_>(ctx, ck.p, wc ? cv->as<uint32_t>() : nullptr, D, (int)k, e.p,
+                                        wc ? ec.as<uint32_t>() : nullptr));
+    sort_records(ctx, W, e.p, et.p, wc ? ec.as<uint32_t>() : nullptr, wc ? ect.as<uint32_t>() : nullptr, 2 * D,
+                 key_passes(k));
+    const uint64_t D2 = unique_records(ctx, W, e.p, wc ? ec.as<uint32_t>() : nullptr, 2 * D, et.p,
+                                       wc ? ect.as<uint32_t>() : nullptr, wc ? REDUCE_SUM : REDUCE_COUNT, false);
+    e.release();
+    ec.release();
+    s.n = D2;
+    s.keys.alloc(D2 * rec);
+    BBK_HIP(hipMemcpyAsync(s.keys.p, et.p, D2 * rec, hipMemcpyDeviceToDevice, ctx->stream));
+    if (wc) {
+        s.counts.alloc(D2 * 4);
+        BBK_HIP(hipMemcpyAsync(s.counts.p, ect.p, D2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    BBK_HIP(hipStreamSynchronize(ctx->stream));
+}
+
 static void check_k(unsigned k) {
     // KMerCounter accepts any k in [1, MAX_K) (projects/kmercount/main.cpp has no parity check)
     BBK_REQUIRE(k >= 1 && k < BBK_MAX_K, BBK_ERR_ARG, "k-mer size %u out of range [1,%d)", k, BBK_MAX_K);
@@ -206,37 +244,8 @@ int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, 
             s->n = D;
             s->keys = std::move(ck);
             if (wc) s->counts = std::move(cv);
-        } else if (D == 0) {
-            s->n = 0;
-            s->keys.alloc(16);
-            if (wc) s->counts.alloc(16);
         } else {
-            const int W = (int)s->W;
-            const size_t rec = (size_t)W * 8;
-            BBK_REQUIRE(2 * D < (1ull << 32), BBK_ERR_ARG, "too many distinct k-mers for one device batch");
-            DevBuf e(2 * D * rec), et(2 * D * rec), ec, ect;
-            if (wc) {
-                ec.alloc(2 * D * 4);
-                ect.alloc(2 * D * 4);
-            }
-            BBK_DISPATCH_W(W, launch_expand<W_>(ctx, ck.p, wc ? cv.as<uint32_t>() : nullptr, D, (int)k, e.p,
-                                                wc ? ec.as<uint32_t>() : nullptr));
-            ck.release();
-            cv.release();
-            sort_records(ctx, W, e.p, et.p, wc ? ec.as<uint32_t>() : nullptr, wc ? ect.as<uint32_t>() : nullptr,
-                         2 * D, key_passes(k));
-            // a k-mer equal to its own RC (even k) appears twice: unique merges it; its count doubles,
-            // as in the reference where both strands of such an occurrence are counted
-            const uint64_t D2 = unique_records(ctx, W, e.p, wc ? ec.as<uint32_t>() : nullptr, 2 * D, et.p,
-                                               wc ? ect.as<uint32_t>() : nullptr, wc ? REDUCE_SUM : REDUCE_COUNT, false);
-            s->n = D2;
-            s->keys.alloc(D2 * rec);
-            BBK_HIP(hipMemcpyAsync(s->keys.p, et.p, D2 * rec, hipMemcpyDeviceToDevice, ctx->stream));
-            if (wc) {
-                s->counts.alloc(D2 * 4);
-                BBK_HIP(hipMemcpyAsync(s->counts.p, ect.p, D2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-            }
-            BBK_HIP(hipStreamSynchronize(ctx->stream));
+            expand_both_strands(ctx, k, ck, wc ? &cv : nullptr, D, *s);
         }
         *out = s.release();
     });
@@ -280,6 +289,21 @@ int bbk_kmerset_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_coun
             BBK_HIP(hipMemcpyAsync(s->counts.p, cb.p, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
         }
         BBK_HIP(hipStreamSynchronize(ctx->stream));
+        *out = s.release();
+    });
+}
+
+int bbk_kmerset_both_strands(bbk_ctx *ctx, const bbk_kmerset *canon, bbk_kmerset **out) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && canon && out, BBK_ERR_ARG, "bbk_kmerset_both_strands: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        auto s = std::make_unique<bbk_kmerset>();
+        s->k = canon->k;
+        s->W = canon->W;
+        s->flags = (canon->flags & ~BBK_CANONICAL) | BBK_BOTH_STRANDS;
+        s->has_counts = canon->has_counts;
+        s->instances = 2 * canon->instances;
+        expand_both_strands(ctx, canon->k, canon->keys, canon->has_counts ? &canon->counts : nullptr, canon->n, *s);
         *out = s.release();
     });
 }

@@ -11,6 +11,8 @@
 
 #include <cstdarg>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "bbk_internal.h"
 #include "kmer_ops.h"
@@ -25,6 +27,63 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 const char *get_error() { return g_err; }
+
+// ---- caching device allocator ---------------------------------------------------------------
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;  // size -> block
+    size_t cached_bytes = 0;
+};
+Pool &pool() {
+    static Pool p;
+    return p;
+}
+constexpr size_t kPoolGranule = 2ull << 20;  // sizes rounded to 2 MiB: identical steps reuse blocks exactly
+}  // namespace
+
+void *pool_alloc(size_t bytes, size_t *granted) {
+    const size_t want = bytes <= 4096 ? 4096 : ((bytes + kPoolGranule - 1) / kPoolGranule) * kPoolGranule;
+    {
+        std::lock_guard<std::mutex> g(pool().mu);
+        auto it = pool().free_blocks.lower_bound(want);
+        // accept a cached block up to 12.5 % larger than asked
+        if (it != pool().free_blocks.end() && it->first <= want + want / 8) {
+            void *p = it->second;
+            *granted = it->first;
+            pool().cached_bytes -= it->first;
+            pool().free_blocks.erase(it);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        pool_trim();  // give cached blocks back and retry once
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        throw Error{e == hipErrorOutOfMemory ? BBK_ERR_NOMEM : BBK_ERR_HIP};
+    }
+    *granted = want;
+    return p;
+}
+
+void pool_free(void *p, size_t bytes) {
+    std::lock_guard<std::mutex> g(pool().mu);
+    pool().free_blocks.emplace(bytes, p);
+    pool().cached_bytes += bytes;
+}
+
+void pool_trim() {
+    std::lock_guard<std::mutex> g(pool().mu);
+    for (auto &kv : pool().free_blocks) (void)hipFree(kv.second);
+    pool().free_blocks.clear();
+    pool().cached_bytes = 0;
+}
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
@@ -700,6 +759,8 @@ int bbk_ctx_destroy(bbk_ctx *ctx) {
     if (!ctx) return BBK_OK;
     (void)hipSetDevice(ctx->device);
     ctx->resolve_pending();
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    bbk::pool_trim();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return BBK_OK;

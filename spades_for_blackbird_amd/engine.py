@@ -16,7 +16,7 @@ SYMBOLS = [
     "bbk_ctx_synchronize", "bbk_ctx_profile_enable", "bbk_ctx_profile_reset", "bbk_ctx_profile_get",
     "bbk_reads_from_ascii", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_count", "bbk_reads_bases",
     "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
-    "bbk_count", "bbk_kmerset_from_device", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k",
+    "bbk_count", "bbk_kmerset_from_device", "bbk_kmerset_both_strands", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k",
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_free",
@@ -66,6 +66,7 @@ def load_library():
     L.bbk_reads_free.argtypes = [vp]
     L.bbk_count.argtypes = [vp, vp, C.c_uint, C.c_uint, C.POINTER(vp)]
     L.bbk_kmerset_from_device.argtypes = [vp, vp, vp, u64, C.c_uint, C.POINTER(vp)]
+    L.bbk_kmerset_both_strands.argtypes = [vp, vp, C.POINTER(vp)]
     L.bbk_words.restype = C.c_uint
     L.bbk_words.argtypes = [C.c_uint]
     L.bbk_kmerset_size.restype = u64
@@ -275,6 +276,11 @@ class KMerSet(_Handle):
     @property
     def instances(self):
         return int(self._L.bbk_kmerset_instances(self._h))
+
+    def both_strands(self):
+        h = C.c_void_p()
+        _check(self._L.bbk_kmerset_both_strands(self.ctx._h, self._h, C.byref(h)))
+        return KMerSet(self.ctx, h)
 
     def export(self, order=ORDER_SORTED, with_counts=False):
         n, nw = len(self), words(self.k)
