@@ -1,0 +1,108 @@
+// extindex.hip -- DeBruijnExtensionIndex on the device.
+//
+// Reference (common/utils/extension_index/kmer_extension_index_builder.hpp:62-106) builds it in
+// four steps: count canonical (k+1)-mers, derive canonical k-mers from them, build a BooPHF over
+// the k-mers, then for every (k+1)-mer do two MPHF lookups + two `omp atomic` byte ORs
+// (FillExtensionsFromIndex :44-59, InOutMask::AddOutgoing/AddIncoming kmer_extension_index.hpp:92-106).
+// Here it is ONE sort-reduce: every k-mer position of every read emits (canonical k-mer, the
+// in/out bits its two neighbouring (k+1)-mers give it, already conjugated when the k-mer is not
+// minimal -- position 7-pos, kmer_extension_index.hpp:67-69); a radix sort by key and a
+// segmented OR give the sorted table (canonical k-mer, InOutMask).  The sorted table itself is
+// the index (prefix table + binary search replaces the MPHF, kmer_index.hpp:85-90).
+// K-mers that never get a bit (reads of length exactly k) are dropped, as in the reference where
+// k-mers only come from (k+1)-mers (kmer_splitters.hpp:160-180).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <memory>
+
+#include "bbk_internal.h"
+#include "kmer_ops.h"
+
+namespace bbk {
+
+void count_canonical(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_mask, bool want_vals, DevBuf &out_keys,
+                     DevBuf &out_vals, uint64_t &n_distinct, uint64_t &n_instances);
+
+__global__ void k_u32_to_u8(const uint32_t *__restrict__ in, uint64_t n, uint8_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint8_t)in[i];
+}
+
+// pref[t] = first index whose top `bits` bits of word 0 are >= t  (t in [0, 2^bits])
+__global__ void k_prefix_table(const uint64_t *__restrict__ keys, int W, uint64_t n, int shift, uint32_t nbins,
+                               uint32_t *__restrict__ pref) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t t = (uint32_t)(keys[i * W] >> shift);
+    const int64_t tp = (i == 0) ? -1 : (int64_t)(keys[(i - 1) * W] >> shift);
+    for (int64_t u = tp + 1; u <= (int64_t)t; ++u) pref[u] = (uint32_t)i;
+    if (i == n - 1)
+        for (uint32_t u = t + 1; u <= nbins; ++u) pref[u] = (uint32_t)n;
+}
+
+void build_prefix_table(bbk_ctx *ctx, bbk_extindex *x) {
+    // ~8 keys per bin; word 0 holds min(2k, 64) populated bits
+    const int w0bits = (x->W == 1) ? (int)(2 * x->k) : 64;
+    int bits = 4;
+    while (bits < 24 && (1ull << (bits + 3)) < x->n) ++bits;
+    bits = std::min(bits, w0bits);
+    x->prefix_bits = (unsigned)bits;
+    const uint32_t nbins = 1u << bits;
+    x->prefix.alloc(((size_t)nbins + 1) * sizeof(uint32_t));
+    if (x->n == 0) {
+        BBK_HIP(hipMemsetAsync(x->prefix.p, 0, ((size_t)nbins + 1) * sizeof(uint32_t), ctx->stream));
+    } else {
+        hipLaunchKernelGGL(k_prefix_table, dim3((unsigned)((x->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           x->keys.as<uint64_t>(), (int)x->W, x->n, w0bits - bits, nbins, x->prefix.as<uint32_t>());
+        check_launch("k_prefix_table");
+    }
+    BBK_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+}  // namespace bbk
+
+using namespace bbk;
+
+extern "C" {
+
+int bbk_extindex_build(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, bbk_extindex **out) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && reads && out, BBK_ERR_ARG, "bbk_extindex_build: NULL argument");
+        // the index is built from (k+1)-mers, so k+1 must be a legal k-mer size too
+        BBK_REQUIRE(k >= 1 && k + 1 < BBK_MAX_K, BBK_ERR_ARG, "k-mer size %u out of range [1,%d)", k, BBK_MAX_K - 1);
+        BBK_HIP(hipSetDevice(ctx->device));
+        auto x = std::make_unique<bbk_extindex>();
+        x->k = k;
+        x->W = words_of(k);
+        DevBuf m32;
+        count_canonical(ctx, reads, k, /*with_mask=*/true, true, x->keys, m32, x->n, x->instances);
+        x->masks.alloc(x->n + 16);
+        if (x->n) {
+            hipLaunchKernelGGL(k_u32_to_u8, dim3((unsigned)((x->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               m32.as<uint32_t>(), x->n, x->masks.as<uint8_t>());
+            check_launch("k_u32_to_u8");
+        }
+        build_prefix_table(ctx, x.get());
+        *out = x.release();
+    });
+}
+
+uint64_t bbk_extindex_size(const bbk_extindex *x) { return x ? x->n : 0; }
+unsigned bbk_extindex_k(const bbk_extindex *x) { return x ? x->k : 0; }
+
+int bbk_extindex_export(bbk_ctx *ctx, const bbk_extindex *x, void *dst_keys, void *dst_masks) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && x, BBK_ERR_ARG, "bbk_extindex_export: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        if (x->n == 0) return;
+        if (dst_keys)
+            BBK_HIP(hipMemcpyAsync(dst_keys, x->keys.p, x->n * x->W * 8, hipMemcpyDefault, ctx->stream));
+        if (dst_masks) BBK_HIP(hipMemcpyAsync(dst_masks, x->masks.p, x->n, hipMemcpyDefault, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+void bbk_extindex_free(bbk_extindex *x) { delete x; }
+
+}  // extern "C"

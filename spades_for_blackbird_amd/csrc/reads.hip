@@ -230,12 +230,15 @@ int bbk_reads_get_ascii(bbk_ctx *ctx, const bbk_reads *r, uint64_t i, char *h_ds
         BBK_REQUIRE(ctx && r && h_dst && len && i < r->n, BBK_ERR_ARG, "bbk_reads_get_ascii: bad argument");
         uint64_t wo[2];
         uint32_t L;
-        BBK_HIP(hipMemcpy(wo, r->d_woff + i, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        BBK_HIP(hipMemcpy(&L, r->d_len + i, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        BBK_HIP(hipMemcpyAsync(wo, r->d_woff + i, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(&L, r->d_len + i, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
         BBK_REQUIRE(L + 1 <= cap, BBK_ERR_ARG, "bbk_reads_get_ascii: buffer too small (%u needed)", L + 1);
         std::vector<uint64_t> w(wo[1] - wo[0] + 1);
         if (wo[1] > wo[0])
-            BBK_HIP(hipMemcpy(w.data(), r->d_words + wo[0], (wo[1] - wo[0]) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            BBK_HIP(hipMemcpyAsync(w.data(), r->d_words + wo[0], (wo[1] - wo[0]) * sizeof(uint64_t),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
         for (uint32_t p = 0; p < L; ++p) h_dst[p] = "ACGT"[(w[p >> 5] >> ((p & 31) << 1)) & 3];
         h_dst[L] = 0;
         *len = L;

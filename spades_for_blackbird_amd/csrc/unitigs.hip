@@ -1,0 +1,645 @@
+// unitigs.hip -- unbranching-path extraction, graph linking and the GFA/FASTA writers.
+//
+// Replaces (reference common/assembly_graph/construction/debruijn_graph_constructor.hpp):
+//   UnbranchingPathExtractor::AddStartDeEdges / StepRightIfPossible / ConstructSequenceWithEdge /
+//     CalculateSequences (:201-245,267-286)  -> k_count_starts / k_fill_starts / k_walk (one thread
+//     per start edge; the sorted (k-mer, mask) table + prefix table replaces the MPHF)
+//   `if (s < !s) continue` (:279)              -> decided in-flight from the two end k-mers (see k_walk)
+//   CleanCondensed (:288-304)                  -> a visited byte per canonical k-mer
+//   CollectLoops / ConstructLoopFromVertex / SplitLoop (:248-265,308-344) -> the (rare) leftover
+//     non-junction k-mers are compacted on the device and walked on the host, sequentially like
+//     the reference
+//   FastGraphFromSequencesConstructor (:390-518): LinkRecord (:400-430) keyed by the canonical end
+//     k-mer's table index, device radix sort, vertices = distinct keys, links = incoming x outgoing
+//   io/graph/gfa_writer.cpp:18-52 and projects/gbuilder/main.cpp:183-192 for the text formats.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "bbk_internal.h"
+#include "kmer_ops.h"
+
+struct bbk_unitigs {
+    unsigned k = 0;
+    uint64_t n = 0, n_loops = 0, n_vertices = 0, n_links = 0;
+    std::vector<char> bases;        // concatenated ACGT
+    std::vector<uint64_t> offsets;  // n + 1
+    std::vector<uint32_t> links;    // 4 per link: from, from_plus, to, to_plus
+};
+
+namespace bbk {
+
+__device__ __host__ inline bool mask_is_junction(uint32_t m) {
+    // InOutMask::IsJunction (kmer_extension_index.hpp:46-58,144-162)
+    return __builtin_popcount(m & 15u) != 1 || __builtin_popcount((m >> 4) & 15u) != 1;
+}
+
+__global__ void k_count_starts(const uint8_t *__restrict__ masks, uint64_t n, uint64_t *__restrict__ cnt) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t m = masks[i];
+    // outgoing edges of the k-mer and of its reverse complement (whose outgoing = this one's incoming)
+    cnt[i] = mask_is_junction(m) ? (uint64_t)__builtin_popcount(m) : 0ull;
+}
+
+// start edge descriptor: idx << 3 | strand << 2 | base   (AddStartDeEdges :214-226: the k-mer's own
+// outgoing edges for next = 0..3, then those of its reverse complement)
+__global__ void k_fill_starts(const uint8_t *__restrict__ masks, uint64_t n, const uint64_t *__restrict__ off,
+                              uint64_t *__restrict__ starts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t m = masks[i];
+    if (!mask_is_junction(m)) return;
+    uint64_t o = off[i];
+    for (uint32_t c = 0; c < 4; ++c)
+        if (m & (1u << c)) starts[o++] = (i << 3) | c;
+    const uint32_t mr = rev8(m);
+    for (uint32_t c = 0; c < 4; ++c)
+        if (mr & (1u << c)) starts[o++] = (i << 3) | 4u | c;
+}
+
+template <int W>
+__device__ inline uint32_t find_kmer(const Key<W> *__restrict__ keys, const uint32_t *__restrict__ pref, int pshift,
+                                     const Key<W> &q) {
+    const uint32_t t = (uint32_t)(q.w[0] >> pshift);
+    uint32_t lo = pref[t], hi = pref[t + 1];
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const Key<W> km = key_load<W>(&keys[mid]);
+        if (key_eq<W>(km, q)) return mid;
+        if (key_less_words<W>(km, q)) lo = mid + 1;
+        else hi = mid;
+    }
+    return 0xFFFFFFFFu;
+}
+
+struct WalkOut {
+    // pass 0
+    uint64_t *keep;      // [E] 0/1
+    uint64_t *ulen;      // [E] k + appended bases if kept else 0
+    // pass 1
+    const uint64_t *uid;   // exclusive scan of keep
+    const uint64_t *boff;  // exclusive scan of ulen
+    char *bases;
+    uint64_t *uoff;        // [U] base offset of unitig
+    uint64_t *rec;         // [2U] link records: (idx<<2 | is_rc<<1 | is_start), ~0 = none
+    uint8_t *visited;      // [n]
+    uint32_t *err;
+};
+
+// One thread per start edge.  PASS 0: length + keep decision (+ visited marks).  PASS 1: write the
+// bases and the link records of kept unitigs.
+//
+// Keep rule (`if (s < !s) continue`, :279): s = x.c....z ; rc(s) starts with rc(z).  If
+// x != rc(z) the first k bases decide.  If x == rc(z) the next base decides: s[k] = c against
+// rc(s)[k] = comp(base preceding z in s); if these agree too, s and rc(s) leave the same junction
+// by the same edge, the walk is deterministic, hence s == rc(s) (self-conjugate edge): keep.
+template <int W, int PASS>
+__global__ __launch_bounds__(256) void k_walk(const Key<W> *__restrict__ keys, const uint8_t *__restrict__ masks,
+                                             const uint32_t *__restrict__ pref, int pshift, uint64_t n, int k,
+                                             const uint64_t *__restrict__ starts, uint64_t E, WalkOut o) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    if (PASS == 1 && o.keep[e] == 0) return;
+    const uint64_t d = starts[e];
+    const uint32_t i = (uint32_t)(d >> 3);
+    const bool s_rc = (d >> 2) & 1;
+    const uint32_t c0 = (uint32_t)(d & 3);
+    const Key<W> canon0 = key_load<W>(&keys[i]);
+    const Key<W> x = key_select<W>(s_rc, kmer_rc<W>(canon0, k), canon0);
+    char *dst = nullptr;
+    if (PASS == 1) {
+        dst = o.bases + o.boff[e];
+        for (int j = 0; j < k; ++j) dst[j] = "ACGT"[kmer_base<W>(x, j)];
+        dst[k] = "ACGT"[c0];
+    }
+    Key<W> cur = kmer_shl<W>(x, k, c0);
+    uint64_t len = 1;
+    uint32_t prev_first = kmer_base<W>(x, 0);
+    uint32_t j = 0xFFFFFFFFu;
+    bool cur_min = true;
+    Key<W> rcur = cur;
+    for (;;) {
+        rcur = kmer_rc<W>(cur, k);
+        cur_min = !kmer_less_nucl<W>(rcur, cur);
+        const Key<W> q = key_select<W>(cur_min, cur, rcur);
+        j = find_kmer<W>(keys, pref, pshift, q);
+        if (j == 0xFFFFFFFFu) {
+            atomicOr(o.err, 1u);
+            return;
+        }
+        uint32_t m = masks[j];
+        if (!cur_min) m = rev8(m);
+        if (mask_is_junction(m)) break;
+        if (PASS == 0) o.visited[j] = 1;
+        const uint32_t c = (uint32_t)__builtin_ctz(m & 15u);
+        prev_first = kmer_base<W>(cur, 0);
+        cur = kmer_shl<W>(cur, k, c);
+        if (PASS == 1) dst[k + len] = "ACGT"[c];
+        ++len;
+        if (len > n + 2) {  // cannot happen on a consistent index: a start edge never re-enters itself
+            atomicOr(o.err, 2u);
+            return;
+        }
+    }
+    if (PASS == 0) {
+        bool keep;
+        if (key_eq<W>(x, rcur)) {
+            const uint32_t other = 3u - prev_first;
+            keep = c0 >= other;
+        } else {
+            keep = kmer_less_nucl<W>(rcur, x);  // rc(s) < s
+        }
+        o.keep[e] = keep ? 1ull : 0ull;
+        o.ulen[e] = keep ? (uint64_t)k + len : 0ull;
+    } else {
+        const uint64_t u = o.uid[e];
+        o.uoff[u] = o.boff[e];
+        const bool selfconj = key_eq<W>(x, rcur) && c0 == 3u - prev_first;
+        // StartLink / EndLink (:432-448): canonical form of the end k-mers, is_rc = k-mer is not it
+        o.rec[2 * u] = ((uint64_t)i << 2) | ((uint64_t)(s_rc ? 1 : 0) << 1) | 1ull;
+        o.rec[2 * u + 1] = selfconj ? ~0ull : (((uint64_t)j << 2) | ((uint64_t)(cur_min ? 0 : 1) << 1));
+    }
+}
+
+__global__ void k_loop_candidates(const uint8_t *__restrict__ masks, const uint8_t *__restrict__ visited, uint64_t n,
+                                  uint64_t *__restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (!mask_is_junction(masks[i]) && !visited[i]) ? 1ull : 0ull;
+}
+
+__global__ void k_compact_candidates(const uint64_t *__restrict__ flag_scan, const uint8_t *__restrict__ masks,
+                                     const uint8_t *__restrict__ visited, uint64_t n, uint32_t *__restrict__ idx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!mask_is_junction(masks[i]) && !visited[i]) idx[flag_scan[i]] = (uint32_t)i;
+}
+
+__global__ void k_edge_ids(uint32_t *__restrict__ ids, uint64_t n2) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n2) ids[i] = (uint32_t)(i >> 1);
+}
+
+// ---- host helpers for the loop path (rare; plain strings) -----------------------------------
+static std::string str_rc(const std::string &s) {
+    std::string r(s.rbegin(), s.rend());
+    for (char &c : r) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+    return r;
+}
+
+static void pack_kmer(const char *s, int k, uint64_t *w, int W) {
+    for (int i = 0; i < W; ++i) w[i] = 0;
+    for (int i = 0; i < k; ++i) {
+        const uint64_t c = s[i] == 'A' ? 0 : s[i] == 'C' ? 1 : s[i] == 'G' ? 2 : 3;
+        w[i >> 5] |= c << ((i & 31) << 1);
+    }
+}
+
+static std::string unpack_kmer(const uint64_t *w, int k) {
+    std::string s((size_t)k, 'A');
+    for (int i = 0; i < k; ++i) s[(size_t)i] = "ACGT"[(w[i >> 5] >> ((i & 31) << 1)) & 3];
+    return s;
+}
+
+struct LoopTable {
+    int k, W;
+    std::vector<uint32_t> idx;     // index in the full table
+    std::vector<uint64_t> keys;    // W words each, ascending
+    std::vector<uint8_t> masks;
+    std::vector<uint8_t> used;
+    // position of an oriented k-mer's canonical form, -1 if absent
+    long find(const std::string &kmer, bool *minimal) const {
+        const std::string r = str_rc(kmer);
+        *minimal = kmer <= r;
+        const std::string &c = *minimal ? kmer : r;
+        uint64_t q[4];
+        pack_kmer(c.data(), k, q, W);
+        size_t lo = 0, hi = idx.size();
+        while (lo < hi) {
+            const size_t mid = lo + (hi - lo) / 2;
+            int cmp = 0;
+            for (int i = 0; i < W && cmp == 0; ++i)
+                cmp = keys[mid * W + i] < q[i] ? -1 : (keys[mid * W + i] > q[i] ? 1 : 0);
+            if (cmp == 0) return (long)mid;
+            if (cmp < 0) lo = mid + 1;
+            else hi = mid;
+        }
+        return -1;
+    }
+};
+
+template <int W>
+static void run_walk(bbk_ctx *ctx, int pass, const bbk_extindex *x, const uint64_t *starts, uint64_t E, WalkOut o) {
+    if (E == 0) return;
+    const int w0bits = (x->W == 1) ? (int)(2 * x->k) : 64;
+    const int pshift = w0bits - (int)x->prefix_bits;
+    KernelTimer t(ctx, pass == 0 ? "walk0" : "walk1", 0);
+    if (pass == 0)
+        hipLaunchKernelGGL((k_walk<W, 0>), dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ctx->stream,
+                           x->keys.as<Key<W>>(), x->masks.as<uint8_t>(), x->prefix.as<uint32_t>(), pshift, x->n,
+                           (int)x->k, starts, E, o);
+    else
+        hipLaunchKernelGGL((k_walk<W, 1>), dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ctx->stream,
+                           x->keys.as<Key<W>>(), x->masks.as<uint8_t>(), x->prefix.as<uint32_t>(), pshift, x->n,
+                           (int)x->k, starts, E, o);
+    check_launch("k_walk");
+}
+
+static void dispatch_walk(bbk_ctx *ctx, int pass, const bbk_extindex *x, const uint64_t *starts, uint64_t E,
+                          WalkOut o) {
+    switch (x->W) {
+        case 1: run_walk<1>(ctx, pass, x, starts, E, o); break;
+        case 2: run_walk<2>(ctx, pass, x, starts, E, o); break;
+        case 3: run_walk<3>(ctx, pass, x, starts, E, o); break;
+        case 4: run_walk<4>(ctx, pass, x, starts, E, o); break;
+        default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %u", x->W);
+    }
+}
+
+struct LinkRec {
+    uint64_t key;
+    uint32_t edge;
+};
+
+// device -> host on the context's stream (a plain hipMemcpy runs on the null stream and would not
+// wait for kernels queued on a non-blocking stream)
+static void d2h(bbk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    BBK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BBK_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
+    const int k = (int)x->k;
+    const uint64_t n = x->n;
+    U.k = x->k;
+    BBK_REQUIRE(k % 2 == 1, BBK_ERR_ARG, "k-mer size must be odd");  // projects/gbuilder/main.cpp:125-126
+    BBK_REQUIRE(n < (1ull << 32) - 2, BBK_ERR_ARG, "extension index too large for one device batch");
+    U.offsets.assign(1, 0);
+    if (n == 0) return;
+
+    // ---- start edges
+    DevBuf cnt((n + 1) * 8);
+    hipLaunchKernelGGL(k_count_starts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       x->masks.as<uint8_t>(), n, cnt.as<uint64_t>());
+    check_launch("k_count_starts");
+    const uint64_t E = exclusive_scan_u64(ctx, cnt.as<uint64_t>(), cnt.as<uint64_t>(), n);
+    DevBuf starts((E + 1) * 8);
+    hipLaunchKernelGGL(k_fill_starts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       x->masks.as<uint8_t>(), n, cnt.as<uint64_t>(), starts.as<uint64_t>());
+    check_launch("k_fill_starts");
+    cnt.release();
+
+    // ---- pass 0: lengths + keep
+    DevBuf keep((E + 1) * 8), ulen((E + 1) * 8), visited(n + 16), err(16);
+    BBK_HIP(hipMemsetAsync(visited.p, 0, n + 16, ctx->stream));
+    BBK_HIP(hipMemsetAsync(err.p, 0, 16, ctx->stream));
+    WalkOut o{};
+    o.keep = keep.as<uint64_t>();
+    o.ulen = ulen.as<uint64_t>();
+    o.visited = visited.as<uint8_t>();
+    o.err = err.as<uint32_t>();
+    dispatch_walk(ctx, 0, x, starts.as<uint64_t>(), E, o);
+    DevBuf uid((E + 1) * 8), boff((E + 1) * 8);
+    const uint64_t NU = exclusive_scan_u64(ctx, keep.as<uint64_t>(), uid.as<uint64_t>(), E);
+    const uint64_t NB = exclusive_scan_u64(ctx, ulen.as<uint64_t>(), boff.as<uint64_t>(), E);
+    uint32_t herr = 0;
+    d2h(ctx, &herr, err.p, 4);
+    BBK_REQUIRE(herr == 0, BBK_ERR_INTERNAL, "unitig walk failed (code %u): extension index is inconsistent", herr);
+    BBK_REQUIRE(NU < (1ull << 31), BBK_ERR_ARG, "too many unitigs for one device batch");
+
+    // ---- pass 1: bases + link records
+    DevBuf bases(NB + 16), uoff((NU + 1) * 8), rec((2 * NU + 2) * 8);
+    o.uid = uid.as<uint64_t>();
+    o.boff = boff.as<uint64_t>();
+    o.bases = bases.as<char>();
+    o.uoff = uoff.as<uint64_t>();
+    o.rec = rec.as<uint64_t>();
+    dispatch_walk(ctx, 1, x, starts.as<uint64_t>(), E, o);
+    d2h(ctx, &herr, err.p, 4);
+    BBK_REQUIRE(herr == 0, BBK_ERR_INTERNAL, "unitig walk (pass 1) failed (code %u)", herr);
+
+    U.bases.resize(NB);
+    U.offsets.resize(NU + 1);
+    if (NB) BBK_HIP(hipMemcpyAsync(U.bases.data(), bases.p, NB, hipMemcpyDeviceToHost, ctx->stream));
+    if (NU) BBK_HIP(hipMemcpyAsync(U.offsets.data(), uoff.p, NU * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BBK_HIP(hipStreamSynchronize(ctx->stream));
+    U.offsets[NU] = NB;
+    starts.release();
+    keep.release();
+    ulen.release();
+    uid.release();
+    boff.release();
+    bases.release();
+
+    // ---- link records: sort by (key, edge) on the device
+    std::vector<LinkRec> recs;
+    if (NU) {
+        DevBuf ids(2 * NU * 4 + 16), rtmp((2 * NU + 2) * 8), itmp(2 * NU * 4 + 16);
+        hipLaunchKernelGGL(k_edge_ids, dim3((unsigned)((2 * NU + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ids.as<uint32_t>(), 2 * NU);
+        check_launch("k_edge_ids");
+        int bits = 2;
+        while ((1ull << (bits - 2)) < n + 1) ++bits;
+        std::vector<PassDesc> passes;
+        for (int s = 0; s < 64; s += 8) {
+            // keys are either < 2^bits or ~0 (no record): sorting all 64 bits keeps ~0 last; passes above
+            // `bits` see only digit 0x00 or 0xFF and are cheap but needed for ~0 to sort last
+            passes.push_back({0, 0, s, 8, 0});
+        }
+        sort_records(ctx, 1, rec.p, rtmp.p, ids.as<uint32_t>(), itmp.as<uint32_t>(), 2 * NU, passes);
+        std::vector<uint64_t> hk(2 * NU);
+        std::vector<uint32_t> he(2 * NU);
+        BBK_HIP(hipMemcpyAsync(hk.data(), rec.p, 2 * NU * 8, hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(he.data(), ids.p, 2 * NU * 4, hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        recs.reserve(2 * NU);
+        for (uint64_t r = 0; r < 2 * NU; ++r) {
+            if (hk[r] == ~0ull) break;
+            recs.push_back({hk[r], he[r]});
+        }
+    }
+    rec.release();
+    uoff.release();
+
+    // ---- perfect loops: leftover non-junction k-mers (CollectLoops :308-344), walked on the host
+    DevBuf flag((n + 1) * 8);
+    hipLaunchKernelGGL(k_loop_candidates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       x->masks.as<uint8_t>(), visited.as<uint8_t>(), n, flag.as<uint64_t>());
+    check_launch("k_loop_candidates");
+    const uint64_t NC = exclusive_scan_u64(ctx, flag.as<uint64_t>(), flag.as<uint64_t>(), n);
+    uint64_t n_paths = NU, n_loops = 0;
+    if (NC) {
+        LoopTable T;
+        T.k = k;
+        T.W = (int)x->W;
+        T.idx.resize(NC);
+        DevBuf cidx(NC * 4 + 16);
+        hipLaunchKernelGGL(k_compact_candidates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           flag.as<uint64_t>(), x->masks.as<uint8_t>(), visited.as<uint8_t>(), n,
+                           cidx.as<uint32_t>());
+        check_launch("k_compact_candidates");
+        d2h(ctx, T.idx.data(), cidx.p, NC * 4);
+        T.keys.resize(NC * T.W);
+        T.masks.resize(NC);
+        T.used.assign(NC, 0);
+        // gather the candidate rows (few): one small copy each would be slow for many loops, so copy
+        // the covering range when it is dense, else row by row
+        std::vector<uint64_t> allk;
+        std::vector<uint8_t> allm;
+        const uint32_t lo = T.idx.front(), hi = T.idx.back();
+        const uint64_t span = (uint64_t)hi - lo + 1;
+        allk.resize(span * T.W);
+        allm.resize(span);
+        d2h(ctx, allk.data(), x->keys.as<uint64_t>() + (uint64_t)lo * T.W, span * T.W * 8);
+        d2h(ctx, allm.data(), x->masks.as<uint8_t>() + lo, span);
+        for (uint64_t c = 0; c < NC; ++c) {
+            const uint64_t r = T.idx[c] - lo;
+            for (int w = 0; w < T.W; ++w) T.keys[c * T.W + w] = allk[r * T.W + w];
+            T.masks[c] = allm[r];
+        }
+        auto oriented_mask = [&](long pos, bool minimal) -> uint32_t {
+            return minimal ? T.masks[(size_t)pos] : rev8(T.masks[(size_t)pos]);
+        };
+        auto emit = [&](const std::string &s) {
+            // records + storage of one loop piece; CleanCondensed(s) and CleanCondensed(rc s)
+            const std::string r = str_rc(s);
+            const std::string &best = (s < r) ? r : s;  // push max(s, rc s) (:330-334)
+            const uint64_t id = U.offsets.size() - 1;
+            U.bases.insert(U.bases.end(), best.begin(), best.end());
+            U.offsets.push_back(U.bases.size());
+            const bool selfconj = best == str_rc(best);
+            for (int is_start = 1; is_start >= 0; --is_start) {
+                if (!is_start && selfconj) continue;
+                const std::string km = is_start ? best.substr(0, (size_t)k) : best.substr(best.size() - (size_t)k);
+                bool minimal;
+                const long pos = T.find(km, &minimal);
+                BBK_REQUIRE(pos >= 0, BBK_ERR_INTERNAL, "loop end k-mer missing from the candidate table");
+                recs.push_back({((uint64_t)T.idx[(size_t)pos] << 2) | ((uint64_t)(minimal ? 0 : 1) << 1) |
+                                    (uint64_t)is_start,
+                                (uint32_t)id});
+            }
+            for (const std::string *t : {&s, &r})
+                for (size_t p = 0; p + (size_t)k <= t->size(); ++p) {
+                    bool minimal;
+                    const long pos = T.find(t->substr(p, (size_t)k), &minimal);
+                    if (pos >= 0) T.used[(size_t)pos] = 1;
+                }
+            ++n_loops;
+        };
+        for (uint64_t c = 0; c < NC; ++c) {
+            if (T.used[c]) continue;
+            // ConstructLoopFromVertex (:255-265) from the canonical k-mer
+            const std::string x0 = unpack_kmer(&T.keys[c * T.W], k);
+            std::string s = x0;
+            std::string cur = x0;
+            uint32_t m = T.masks[c];
+            for (;;) {
+                const int cb = __builtin_ctz(m & 15u);
+                cur = cur.substr(1) + "ACGT"[cb];
+                if (cur == x0) {  // edge (prev -> x0) closes the cycle: its base is appended, then stop
+                    s.push_back("ACGT"[cb]);
+                    break;
+                }
+                s.push_back("ACGT"[cb]);
+                bool minimal;
+                const long pos = T.find(cur, &minimal);
+                BBK_REQUIRE(pos >= 0, BBK_ERR_INTERNAL, "loop walk left the candidate set");
+                m = oriented_mask(pos, minimal);
+                BBK_REQUIRE(!mask_is_junction(m), BBK_ERR_INTERNAL, "loop walk reached a junction");
+                BBK_REQUIRE(s.size() <= 2 * NC + (size_t)k + 1, BBK_ERR_INTERNAL, "loop walk does not close");
+            }
+            // the reference string ends when the walk is back on its first EDGE: x0 . (cycle bases) with
+            // the closing k-mer x0 spelled again minus ... -> length = cycle + k  (:232-241)
+            // s currently = x0 + one base per cycle edge (cycle edges = n_cyc) -> length k + n_cyc: equal.
+            // SplitLoop (:248-252) on the first (k+1)-mer equal to its own reverse complement
+            size_t split = std::string::npos;
+            for (size_t p = 0; p + (size_t)k + 1 <= s.size(); ++p) {
+                const std::string e = s.substr(p, (size_t)k + 1);
+                if (e == str_rc(e)) {
+                    split = p;
+                    break;
+                }
+            }
+            if (split == std::string::npos) {
+                emit(s);
+            } else {
+                emit(s.substr(split, (size_t)k + 1));
+                emit(s.substr(split + 1, s.size() - (size_t)k - (split + 1)) + s.substr(0, split + (size_t)k));
+            }
+        }
+        std::stable_sort(recs.begin(), recs.end(), [](const LinkRec &a, const LinkRec &b) {
+            return a.key != b.key ? a.key < b.key : a.edge < b.edge;
+        });
+    }
+    U.n = n_paths + n_loops;
+    U.n_loops = n_loops;
+
+    // ---- vertices + links (gfa_writer.cpp:43-52 over construction_helper.hpp:80-90)
+    std::vector<uint8_t> selfconj(U.n, 0);
+    {
+        // an edge with a start record but no end record is self-conjugate
+        std::vector<uint8_t> has_end(U.n, 0);
+        for (const LinkRec &r : recs)
+            if (!(r.key & 1)) has_end[r.edge] = 1;
+        for (uint64_t i = 0; i < U.n; ++i) selfconj[i] = !has_end[i];
+    }
+    uint64_t nv = 0;
+    for (size_t p = 0; p < recs.size();) {
+        size_t q = p;
+        const uint64_t h = recs[p].key >> 2;
+        while (q < recs.size() && (recs[q].key >> 2) == h) ++q;
+        ++nv;
+        for (size_t a = p; a < q; ++a) {
+            const bool a_start = recs[a].key & 1, a_rc = (recs[a].key >> 1) & 1;
+            if (!((!a_start && !a_rc) || (a_start && a_rc))) continue;  // incoming at the canonical vertex
+            const uint32_t ea = recs[a].edge;
+            const uint32_t oa = (!a_start || selfconj[ea]) ? 1u : 0u;
+            for (size_t b = p; b < q; ++b) {
+                const bool b_start = recs[b].key & 1, b_rc = (recs[b].key >> 1) & 1;
+                if (!((b_start && !b_rc) || (!b_start && b_rc))) continue;  // outgoing
+                const uint32_t eb = recs[b].edge;
+                const uint32_t ob = (b_start || selfconj[eb]) ? 1u : 0u;
+                U.links.push_back(ea);
+                U.links.push_back(oa);
+                U.links.push_back(eb);
+                U.links.push_back(ob);
+            }
+        }
+        p = q;
+    }
+    U.n_vertices = nv;
+    U.n_links = U.links.size() / 4;
+}
+
+}  // namespace bbk
+
+using namespace bbk;
+
+extern "C" {
+
+int bbk_unitigs_build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs **out) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && x && out, BBK_ERR_ARG, "bbk_unitigs_build: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        auto u = std::make_unique<bbk_unitigs>();
+        build(ctx, x, *u);
+        *out = u.release();
+    });
+}
+
+uint64_t bbk_unitigs_count(const bbk_unitigs *u) { return u ? u->n : 0; }
+uint64_t bbk_unitigs_loops(const bbk_unitigs *u) { return u ? u->n_loops : 0; }
+uint64_t bbk_unitigs_total_bases(const bbk_unitigs *u) { return u ? u->bases.size() : 0; }
+uint64_t bbk_unitigs_vertices(const bbk_unitigs *u) { return u ? u->n_vertices : 0; }
+uint64_t bbk_unitigs_links(const bbk_unitigs *u) { return u ? u->n_links : 0; }
+
+int bbk_unitigs_export(bbk_ctx *ctx, const bbk_unitigs *u, char *h_bases, uint64_t *h_offsets) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && u, BBK_ERR_ARG, "bbk_unitigs_export: NULL argument");
+        if (h_bases && !u->bases.empty()) memcpy(h_bases, u->bases.data(), u->bases.size());
+        if (h_offsets) memcpy(h_offsets, u->offsets.data(), u->offsets.size() * sizeof(uint64_t));
+    });
+}
+
+int bbk_unitigs_export_links(bbk_ctx *ctx, const bbk_unitigs *u, uint32_t *h_links) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && u && (u->links.empty() || h_links), BBK_ERR_ARG, "bbk_unitigs_export_links: NULL argument");
+        if (!u->links.empty()) memcpy(h_links, u->links.data(), u->links.size() * sizeof(uint32_t));
+    });
+}
+
+static size_t fmt_u64(char *dst, uint64_t v) {
+    char tmp[24];
+    size_t n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    for (size_t i = 0; i < n; ++i) dst[i] = tmp[n - 1 - i];
+    return n;
+}
+
+int bbk_unitigs_write_gfa(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && u && path, BBK_ERR_ARG, "bbk_unitigs_write_gfa: NULL argument");
+        // S\t<id>\t<seq>\tDP:f:<cov>\tKC:i:<kc>\n with id = 3 + 2i (graph_core.hpp:228; edge i gets
+        // min_id + 2i, debruijn_graph_constructor.hpp:457-458); coverage is 0 without -c.
+        const uint64_t n = u->n;
+        std::vector<uint64_t> pos(n + 1, 0);
+        static const char tail[] = "\tDP:f:0\tKC:i:0\n";
+        const size_t tail_len = sizeof(tail) - 1;
+        for (uint64_t i = 0; i < n; ++i) {
+            char tmp[24];
+            const size_t idl = fmt_u64(tmp, 3 + 2 * i);
+            pos[i + 1] = pos[i] + 2 + idl + 1 + (u->offsets[i + 1] - u->offsets[i]) + tail_len;
+        }
+        std::vector<char> buf(pos[n]);
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = 0; i < n; ++i) {
+            char *d = buf.data() + pos[i];
+            *d++ = 'S';
+            *d++ = '\t';
+            d += fmt_u64(d, 3 + 2 * i);
+            *d++ = '\t';
+            const uint64_t len = u->offsets[i + 1] - u->offsets[i];
+            memcpy(d, u->bases.data() + u->offsets[i], len);
+            d += len;
+            memcpy(d, tail, tail_len);
+        }
+        FILE *f = fopen(path, "wb");
+        BBK_REQUIRE(f != nullptr, BBK_ERR_IO, "cannot open %s for writing", path);
+        bool ok = buf.empty() || fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        // L\t<e1>\t<+|->\t<e2>\t<+|->\t<k>M\n
+        std::string lines;
+        lines.reserve(1 << 20);
+        char num[24];
+        for (uint64_t l = 0; l < u->n_links && ok; ++l) {
+            const uint32_t *r = &u->links[4 * l];
+            lines += "L\t";
+            lines.append(num, fmt_u64(num, 3 + 2 * (uint64_t)r[0]));
+            lines += r[1] ? "\t+\t" : "\t-\t";
+            lines.append(num, fmt_u64(num, 3 + 2 * (uint64_t)r[2]));
+            lines += r[3] ? "\t+\t" : "\t-\t";
+            lines.append(num, fmt_u64(num, u->k));
+            lines += "M\n";
+            if (lines.size() > (1u << 20)) {
+                ok = fwrite(lines.data(), 1, lines.size(), f) == lines.size();
+                lines.clear();
+            }
+        }
+        if (ok && !lines.empty()) ok = fwrite(lines.data(), 1, lines.size(), f) == lines.size();
+        const int cl = fclose(f);
+        BBK_REQUIRE(ok && cl == 0, BBK_ERR_IO, "short write to %s", path);
+    });
+}
+
+int bbk_unitigs_write_fasta(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && u && path, BBK_ERR_ARG, "bbk_unitigs_write_fasta: NULL argument");
+        // >EDGE_<i+1>_length_<len> + 60-column wrapped sequence (projects/gbuilder/main.cpp:183-192,
+        // io/reads/header_naming.hpp:14-20, osequencestream.hpp:22-28)
+        FILE *f = fopen(path, "wb");
+        BBK_REQUIRE(f != nullptr, BBK_ERR_IO, "cannot open %s for writing", path);
+        bool ok = true;
+        for (uint64_t i = 0; i < u->n && ok; ++i) {
+            const uint64_t len = u->offsets[i + 1] - u->offsets[i];
+            ok = fprintf(f, ">EDGE_%llu_length_%llu\n", (unsigned long long)(i + 1), (unsigned long long)len) > 0;
+            for (uint64_t cur = 0; cur < len && ok; cur += 60) {
+                const uint64_t w = std::min<uint64_t>(60, len - cur);
+                ok = fwrite(u->bases.data() + u->offsets[i] + cur, 1, w, f) == w && fputc('\n', f) != EOF;
+            }
+        }
+        const int cl = fclose(f);
+        BBK_REQUIRE(ok && cl == 0, BBK_ERR_IO, "short write to %s", path);
+    });
+}
+
+void bbk_unitigs_free(bbk_unitigs *u) { delete u; }
+
+}  // extern "C"
