@@ -73,6 +73,7 @@ def main():
     import torch
     import torch.distributed as dist
     import spades_for_blackbird_amd as B
+    from spades_for_blackbird_amd import distributed as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -102,22 +103,7 @@ def main():
             s.export_to(out, B.ORDER_REFERENCE_BUCKETS16)
             s.free()
             return n, out
-        c = ctx.count(reads, k, B.CANONICAL)
-        n = len(c)
-        send = torch.empty((n, nw), dtype=torch.int64, device=dev)
-        counts = c.export_by_owner(world, dst_keys=send)
-        c.free()
-        send_counts = torch.tensor([int(x) for x in counts], dtype=torch.int64, device=dev)
-        recv_counts = torch.empty(world, dtype=torch.int64, device=dev)
-        dist.all_to_all_single(recv_counts, send_counts)  # 8x8 size matrix (tiny)
-        rc = [int(x) for x in recv_counts.tolist()]
-        recv = torch.empty((sum(rc), nw), dtype=torch.int64, device=dev)
-        # the one data-path collective: personalised all-to-all over xGMI
-        dist.all_to_all_single(recv.view(-1), send.view(-1), [x * nw for x in rc], [int(x) * nw for x in counts])
-        torch.cuda.current_stream().synchronize()
-        shard = ctx.kmerset_from_device(recv, sum(rc), k)
-        both = shard.both_strands()
-        shard.free()
+        both = D.sharded_count(ctx, reads, k, both_strands=True)
         n2 = len(both)
         out = torch.empty((n2, nw), dtype=torch.int64, device=dev)
         both.export_to(out, B.ORDER_REFERENCE_BUCKETS16)

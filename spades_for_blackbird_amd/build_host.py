@@ -1,0 +1,35 @@
+"""Builds the C++ host programs (the two CLI drop-ins) against libbbk.so with g++ (in-tree)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HOST = os.path.join(HERE, "host")
+BIN = os.path.join(HERE, "bin")
+PROGRAMS = {"spades-kmercount": "kmercount_main.cpp", "spades-gbuilder": "gbuilder_main.cpp",
+            "bbk-fastx-dump": "fastx_dump_main.cpp"}
+HEADERS = ["common.hpp", "dataset.hpp", "fastx.hpp"]
+
+
+def build(force=False, verbose=False):
+    os.makedirs(BIN, exist_ok=True)
+    out = []
+    deps = [os.path.join(HOST, h) for h in HEADERS] + [os.path.join(HERE, "..", "include", "bbk.h"),
+                                                      os.path.join(HERE, "libbbk.so")]
+    for name, src in PROGRAMS.items():
+        exe = os.path.join(BIN, name)
+        srcp = os.path.join(HOST, src)
+        stale = not os.path.exists(exe) or any(os.path.exists(d) and os.path.getmtime(d) > os.path.getmtime(exe)
+                                               for d in deps + [srcp])
+        if force or stale:
+            cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", exe, srcp, "-L" + HERE, "-lbbk", "-lz",
+                   "-Wl,-rpath,$ORIGIN/.."]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        out.append(exe)
+    return out
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

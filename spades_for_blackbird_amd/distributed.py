@@ -1,0 +1,77 @@
+"""Multi-GPU sharding of the k-mer set: one process per GPU, k-mers owned by
+owner(key) = mulhi(mix64(key words), nranks); ONE all_to_all_single carries every distinct
+canonical k-mer to its owner after the local count.  The collective goes through
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests);
+everything else is the C ABI.
+"""
+import numpy as np
+
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+_SEED = np.uint64(0x9E3779B97F4A7C15)
+
+
+def owner_mix(keys):
+    """numpy mirror of csrc/kmer_ops.h owner_mix (keys: uint64[n, W])."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    x = np.full(keys.shape[0], _SEED, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for i in range(keys.shape[1]):
+            x = x ^ keys[:, i]
+            x = x ^ (x >> np.uint64(30))
+            x = x * _M1
+            x = x ^ (x >> np.uint64(27))
+            x = x * _M2
+            x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def owner_of(keys, nranks):
+    """owner rank of every key: (mix * nranks) >> 64."""
+    h = owner_mix(keys)
+    hi, lo = h >> np.uint64(32), h & np.uint64(0xFFFFFFFF)
+    n = np.uint64(nranks)
+    # (h * n) >> 64 with 32-bit limbs (nranks < 2^32)
+    t = (lo * n) >> np.uint64(32)
+    return ((hi * n + t) >> np.uint64(32)).astype(np.int64)
+
+
+def exchange_by_owner(send, send_counts, words, group=None):
+    """send: int64 tensor [n, words] grouped by owner; send_counts: per-owner record counts.
+    Returns (recv tensor [m, words], recv_counts list).  Two collectives: the tiny count matrix and
+    the payload (the only data-path collective)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = send.device
+    sc = torch.tensor([int(x) for x in send_counts], dtype=torch.int64, device=dev)
+    rc = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(rc, sc, group=group)
+    rcl = [int(x) for x in rc.tolist()]
+    recv = torch.empty((sum(rcl), words), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv.view(-1), send.contiguous().view(-1), [x * words for x in rcl],
+                           [int(x) * words for x in send_counts], group=group)
+    return recv, rcl
+
+
+def sharded_count(ctx, reads, k, both_strands=True, group=None):
+    """Count on every rank, exchange distinct canonical k-mers by owner, merge-unique the shard and
+    (optionally) expand it to both strands.  Returns the rank's KMerSet shard."""
+    import torch
+    import torch.distributed as dist
+    from . import engine as E
+    world = dist.get_world_size(group)
+    nw = E.words(k)
+    dev = torch.device("cuda", ctx.device)
+    c = ctx.count(reads, k, E.CANONICAL)
+    send = torch.empty((len(c), nw), dtype=torch.int64, device=dev)
+    counts = c.export_by_owner(world, dst_keys=send)
+    c.free()
+    recv, rcl = exchange_by_owner(send, counts, nw, group)
+    torch.cuda.current_stream().synchronize()
+    shard = ctx.kmerset_from_device(recv, sum(rcl), k)
+    if not both_strands:
+        return shard
+    both = shard.both_strands()
+    shard.free()
+    return both

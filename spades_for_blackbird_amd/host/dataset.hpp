@@ -1,0 +1,106 @@
+// dataset.hpp -- the dataset description the two CLIs accept: a single FASTA/FASTQ(.gz) file or a
+// YAML list of libraries with the keys the reference's SequencingLibraryBase::yamlize maps
+// (common/pipeline/library.cpp:78-87: type, orientation, "left reads", "right reads",
+// "interlaced reads", "merged reads", "single reads"); relative paths are resolved against the
+// YAML file's directory (library.cpp:135-155).  Only what these two tools need is parsed: the flat
+// "- key: [a, b]" / "- key:\n    - a" forms that spades.py and the reference's configs write.
+#pragma once
+
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace bbkhost {
+
+inline std::string trim(const std::string &s) {
+    size_t a = s.find_first_not_of(" \t\r\n");
+    if (a == std::string::npos) return "";
+    size_t b = s.find_last_not_of(" \t\r\n");
+    return s.substr(a, b - a + 1);
+}
+
+inline std::string unquote(std::string s) {
+    s = trim(s);
+    if (s.size() >= 2 && ((s.front() == '"' && s.back() == '"') || (s.front() == '\'' && s.back() == '\'')))
+        s = s.substr(1, s.size() - 2);
+    return s;
+}
+
+inline std::string dirname_of(const std::string &p) {
+    size_t s = p.find_last_of('/');
+    return s == std::string::npos ? std::string(".") : p.substr(0, s);
+}
+
+inline bool ends_with(const std::string &s, const std::string &suf) {
+    return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+// Returns every read file of every library, in library order (left, right, interlaced, merged, single).
+inline bool load_dataset_yaml(const std::string &path, std::vector<std::string> &files, std::string &err) {
+    std::ifstream in(path);
+    if (!in) {
+        err = "cannot open dataset file " + path;
+        return false;
+    }
+    const std::string dir = dirname_of(path);
+    struct Lib { std::vector<std::string> v[5]; };
+    std::vector<Lib> libs;
+    static const char *keys[5] = {"left reads", "right reads", "interlaced reads", "merged reads", "single reads"};
+    int cur_key = -1;
+    std::string line;
+    auto add = [&](int key, std::string f) {
+        f = unquote(f);
+        if (f.empty()) return;
+        if (f[0] != '/') f = dir + "/" + f;
+        libs.back().v[key].push_back(f);
+    };
+    while (std::getline(in, line)) {
+        std::string t = trim(line);
+        if (t.empty() || t[0] == '#') continue;
+        bool new_item = false;
+        if (t[0] == '-' && (t.size() == 1 || t[1] == ' ')) {
+            // either a new library ("- key: ...") or a list element ("- path")
+            std::string rest = trim(t.substr(1));
+            if (rest.find(':') != std::string::npos && rest[0] != '/' && rest[0] != '.') {
+                size_t indent = line.find('-');
+                if (indent <= 1 || libs.empty()) { libs.emplace_back(); new_item = true; }
+                t = rest;
+            } else {
+                if (cur_key >= 0 && !libs.empty()) add(cur_key, rest);
+                continue;
+            }
+        }
+        (void)new_item;
+        size_t colon = t.find(':');
+        if (colon == std::string::npos) continue;
+        if (libs.empty()) libs.emplace_back();
+        std::string key = unquote(t.substr(0, colon));
+        std::string val = trim(t.substr(colon + 1));
+        cur_key = -1;
+        for (int i = 0; i < 5; ++i)
+            if (key == keys[i]) cur_key = i;
+        if (cur_key < 0) continue;  // type / orientation / number: not needed on this path
+        if (!val.empty() && val[0] == '[') {
+            size_t e = val.find(']');
+            std::string inner = val.substr(1, e == std::string::npos ? std::string::npos : e - 1);
+            std::stringstream ss(inner);
+            std::string item;
+            while (std::getline(ss, item, ',')) add(cur_key, item);
+            cur_key = -1;
+        } else if (!val.empty()) {
+            add(cur_key, val);
+            cur_key = -1;
+        }
+    }
+    for (const Lib &l : libs)
+        for (int i = 0; i < 5; ++i)
+            for (const std::string &f : l.v[i]) files.push_back(f);
+    if (files.empty()) {
+        err = "no read files found in " + path;
+        return false;
+    }
+    return true;
+}
+
+}  // namespace bbkhost

@@ -1,0 +1,130 @@
+// fastx.hpp -- FASTA/FASTQ(.gz) reader of the host side (C++ over zlib), the input end of the two
+// CLIs.  Behaviour follows the reference's FastaFastqGzParser over the vendored kseq
+// (common/io/reads/fasta_fastq_gz_parser.hpp:64-80,113-136; ext/include/kseq/kseq.h):
+//   * '>' or '@' starts a record; the name ends at the first white space;
+//   * sequence lines are concatenated until the next '>' / '@' / '+' (multi-line FASTA and FASTQ);
+//   * bases are upper-cased at parse time (kseq.h:193-194);
+//   * a '+' line starts the quality, read until it is as long as the sequence; a quality string of
+//     another length makes the parser stop: the stream just ends there (kseq.h:209,212 returns -2,
+//     fasta_fastq_gz_parser.hpp:130-136 treats any negative value as end of file).
+// Names and qualities are dropped (the path only needs bases, read_converter.cpp:76).
+#pragma once
+
+#include <zlib.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace bbkhost {
+
+struct ReadBatch {
+    std::string bases;              // concatenated read sequences
+    std::vector<uint64_t> offsets;  // n + 1
+    ReadBatch() : offsets(1, 0) {}
+    uint64_t size() const { return offsets.size() - 1; }
+    void clear() {
+        bases.clear();
+        offsets.assign(1, 0);
+    }
+};
+
+class FastxReader {
+  public:
+    explicit FastxReader(const std::string &path) : path_(path) { fp_ = gzopen(path.c_str(), "r"); if (fp_) gzbuffer(fp_, 1 << 20); }
+    ~FastxReader() { if (fp_) gzclose(fp_); }
+    FastxReader(const FastxReader &) = delete;
+    FastxReader &operator=(const FastxReader &) = delete;
+    bool is_open() const { return fp_ != nullptr; }
+
+    // Appends up to max_reads records (and at most max_bases bases) to batch; returns the number read.
+    uint64_t read(ReadBatch &batch, uint64_t max_reads, uint64_t max_bases) {
+        uint64_t got = 0;
+        while (!eof_ && got < max_reads && batch.bases.size() < max_bases) {
+            if (!next(batch.bases)) break;
+            batch.offsets.push_back(batch.bases.size());
+            ++got;
+        }
+        return got;
+    }
+
+  private:
+    int getc_() {
+        if (pos_ >= len_) {
+            if (eof_in_) return -1;
+            len_ = gzread(fp_, buf_, sizeof(buf_));
+            pos_ = 0;
+            if (len_ <= 0) {
+                eof_in_ = true;
+                len_ = 0;
+                return -1;
+            }
+        }
+        return (unsigned char)buf_[pos_++];
+    }
+    // reads the rest of the current line into dst (without the newline); false at end of input
+    bool getline_(std::string *dst) {
+        int c;
+        bool any = false;
+        while ((c = getc_()) != -1) {
+            any = true;
+            if (c == '\n') return true;
+            if (dst && c != '\r') dst->push_back((char)c);
+        }
+        return any;
+    }
+    bool next(std::string &out) {
+        int c;
+        if (last_char_ == 0) {  // jump to the next header line
+            while ((c = getc_()) != -1 && c != '>' && c != '@') {}
+            if (c == -1) { eof_ = true; return false; }
+            last_char_ = c;
+        }
+        getline_(nullptr);  // name + comment
+        const size_t start = out.size();
+        // sequence lines
+        while ((c = getc_()) != -1 && c != '>' && c != '+' && c != '@') {
+            if (c == '\n') continue;
+            out.push_back((char)c);
+            std::string rest;
+            getline_(&rest);
+            out += rest;
+        }
+        // every character of a sequence line is kept and upper-cased (kseq.h:190-194)
+        for (size_t r = start; r < out.size(); ++r) {
+            const unsigned char ch = (unsigned char)out[r];
+            if (ch >= 'a' && ch <= 'z') out[r] = (char)(ch - 32);
+        }
+        if (c == '>' || c == '@') last_char_ = c;
+        else last_char_ = 0;
+        if (c != '+') {
+            if (c == -1) eof_ = eof_in_;
+            return true;  // FASTA record
+        }
+        const size_t seq_len = out.size() - start;
+        getline_(nullptr);  // rest of the '+' line
+        size_t qlen = 0;
+        std::string q;
+        while (qlen < seq_len) {
+            q.clear();
+            if (!getline_(&q)) break;
+            qlen += q.size();
+        }
+        last_char_ = 0;
+        if (qlen != seq_len) {  // truncated quality string: the reference stops here
+            out.resize(start);
+            eof_ = true;
+            return false;
+        }
+        return true;
+    }
+
+    std::string path_;
+    gzFile fp_ = nullptr;
+    char buf_[1 << 16];
+    int pos_ = 0, len_ = 0;
+    bool eof_in_ = false, eof_ = false;
+    int last_char_ = 0;
+};
+
+}  // namespace bbkhost

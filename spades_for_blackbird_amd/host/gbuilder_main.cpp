@@ -1,0 +1,124 @@
+// spades-gbuilder drop-in: same argv contract as the reference tool (projects/gbuilder/main.cpp:47-87)
+//   <dataset yaml | fasta/fastq> <output> [-k <int=21>] [-c] [-t <int>] [-tmp-dir <dir>] [-b <bytes>]
+//   one of --unitigs (default) | --fastg | --gfa | --spades            (+ --device <int>, ours)
+// and the same flow (:103-237): reads -> extension index -> unbranching paths + loops ->
+// unitig FASTA or graph -> GFA, with every step behind the C ABI (include/bbk.h).
+// -t/-tmp-dir/-b are accepted for compatibility (no temp files, no per-thread buffers here).
+// --fastg, --spades and -c are SURVEY 8(f) "next" rows and are refused with a clear message.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace bbkhost;
+
+static void usage(const char *argv0) {
+    printf("SYNOPSIS\n        %s <dataset description (in YAML) or input FASTA file> <output filename> [-k <value>] [-c]\n"
+           "           [-t <value>] [-tmp-dir <dir>] [-b <value>] [--unitigs|--fastg|--gfa|--spades]\n\n"
+           "OPTIONS\n"
+           "        -k <value>  k-mer length to use\n"
+           "        -c          infer coverage\n"
+           "        -t <value>  # of threads to use\n"
+           "        -tmp-dir <dir>\n                    scratch directory to use\n"
+           "        -b <value>  sorting buffer size, per thread\n"
+           "        --unitigs   produce unitigs (default)\n"
+           "        --fastg     produce graph in FASTG format\n"
+           "        --gfa       produce graph in GFA1 format\n"
+           "        --spades    produce graph in SPAdes internal format\n"
+           "        --device <value>  GPU to use (default 0)\n",
+           argv0);
+}
+
+int main(int argc, char **argv) {
+    unsigned k = 21, device = 0;
+    bool coverage = false, bad = false;
+    enum { UNITIGS, FASTG, GFA, SPADES } mode = UNITIGS;
+    int modes_given = 0;
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        unsigned long long v = 0;
+        auto need = [&](unsigned long long *x) { return i + 1 < argc && parse_uint(argv[++i], x); };
+        if (a == "-k") { if (need(&v)) k = (unsigned)v; else bad = true; }
+        else if (a == "-c") coverage = true;
+        else if (a == "-t") { if (!need(&v)) bad = true; }
+        else if (a == "-b") { if (!need(&v)) bad = true; }
+        else if (a == "--device") { if (need(&v)) device = (unsigned)v; else bad = true; }
+        else if (a == "-tmp-dir") { if (i + 1 < argc) ++i; else bad = true; }
+        else if (a == "--unitigs") { mode = UNITIGS; ++modes_given; }
+        else if (a == "--fastg") { mode = FASTG; ++modes_given; }
+        else if (a == "--gfa") { mode = GFA; ++modes_given; }
+        else if (a == "--spades") { mode = SPADES; ++modes_given; }
+        else if (!a.empty() && a[0] == '-' && a.size() > 1) bad = true;
+        else pos.push_back(a);
+    }
+    if (bad || pos.size() != 2 || modes_given > 1) {  // projects/gbuilder/main.cpp:82-86
+        usage(argv[0]);
+        return 1;
+    }
+    const std::string file = pos[0], outfile = pos[1];
+
+    info("Starting SPAdes standalone graph builder (MI355X, %s)", bbk_version());
+    // projects/gbuilder/main.cpp:121-126
+    if (k < 1) fatal("k-mer size %u is too low", k);
+    if (k >= BBK_MAX_K) fatal("k-mer size %u is too high, recompile with larger SPADES_MAX_K option", k);
+    if (k % 2 == 0) fatal("k-mer size must be odd");
+    info("K-mer length set to %u", k);
+    switch (mode) {
+        case UNITIGS: info("Producing unitigs only"); break;
+        case FASTG: info("Producing graph in FASTG format"); break;
+        case GFA: info("Producing graph in GFA1 format"); break;
+        case SPADES: info("Producing graph in SPAdes internal format"); break;
+    }
+    if (mode == FASTG || mode == SPADES)
+        fatal("this build writes --unitigs and --gfa; FASTG / SPAdes-binary output is not implemented yet");
+    if (coverage) fatal("this build does not infer coverage (-c) yet");
+
+    // LoadDataset (:89-101)
+    std::vector<std::string> files;
+    if (ends_with(file, ".yaml")) {
+        std::string err;
+        if (!load_dataset_yaml(file, files, err)) fatal("%s", err.c_str());
+    } else {
+        FILE *f = fopen(file.c_str(), "rb");
+        if (!f) fatal("Dataset description file: %s does not exist or is not a valid YAML file", file.c_str());
+        fclose(f);
+        files.push_back(file);
+    }
+
+    bbk_ctx *ctx = nullptr;
+    check(bbk_ctx_create((int)device, &ctx), "bbk_ctx_create");
+    uint64_t n_reads = 0;
+    bbk_reads *reads = load_reads(ctx, files, &n_reads);
+    info("Used %llu reads", (unsigned long long)n_reads);
+
+    // Step 1: build extension index (:169-172)
+    bbk_extindex *ext = nullptr;
+    check(bbk_extindex_build(ctx, reads, k, &ext), "bbk_extindex_build");
+    info("K-mer counting done. There are %llu kmers in total.", (unsigned long long)bbk_extindex_size(ext));
+    info("Building k-mer extensions from k+1-mers finished.");
+
+    // Step 2: extract unbranching paths (:175-181)
+    bbk_unitigs *u = nullptr;
+    check(bbk_unitigs_build(ctx, ext, &u), "bbk_unitigs_build");
+    info("Extracting unbranching paths finished. %llu sequences extracted",
+         (unsigned long long)(bbk_unitigs_count(u) - bbk_unitigs_loops(u)));
+    info("Collecting perfect loops finished. %llu loops collected", (unsigned long long)bbk_unitigs_loops(u));
+
+    if (mode == UNITIGS) {
+        info("Saving unitigs to %s", outfile.c_str());
+        check(bbk_unitigs_write_fasta(ctx, u, outfile.c_str()), "bbk_unitigs_write_fasta");
+    } else {
+        info("Total %llu edges to create", (unsigned long long)(2 * bbk_unitigs_count(u)));
+        info("Total %llu vertices to create", (unsigned long long)bbk_unitigs_vertices(u));
+        info("Saving graph to %s", outfile.c_str());
+        check(bbk_unitigs_write_gfa(ctx, u, outfile.c_str()), "bbk_unitigs_write_gfa");
+    }
+    bbk_unitigs_free(u);
+    bbk_extindex_free(ext);
+    bbk_reads_free(reads);
+    bbk_ctx_destroy(ctx);
+    info("SPAdes standalone graph builder finished");
+    return 0;
+}

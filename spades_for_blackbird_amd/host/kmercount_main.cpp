@@ -1,0 +1,91 @@
+// spades-kmercount drop-in: same argv contract and the same <workdir>/final_kmers file as the
+// reference tool (projects/kmercount/main.cpp:124-184 for the flags, :186-228 for the flow), with
+// the splitter + KMerDiskCounter replaced by the MI355X engine behind the C ABI (include/bbk.h).
+//   -k/--kmer <int=21>  -d/--dataset <yaml>  -t/--threads <int>  -w/--workdir <dir>
+//   -b/--bufsize <bytes>  -h/--help  [input files...]        (+ --device <int>, ours)
+// -t and -b are accepted for compatibility; the device path has no per-thread sort buffers.
+#include <cerrno>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <sys/stat.h>
+
+#include "common.hpp"
+
+using namespace bbkhost;
+
+static void usage(const char *argv0) {
+    printf("SYNOPSIS\n        %s [-k <value>] [-d <dir>] [-t <value>] [-w <dir>] [-b <value>] [-h] [<input files>]...\n\n"
+           "OPTIONS\n"
+           "        -k, --kmer <value>      K-mer length\n"
+           "        -d, --dataset <dir>     Dataset description (in YAML), input files ignored\n"
+           "        -t, --threads <value>   # of threads to use\n"
+           "        -w, --workdir <dir>     Working directory to use\n"
+           "        -b, --bufsize <value>   Sorting buffer size, per thread\n"
+           "        -h, --help              Show help\n"
+           "        --device <value>        GPU to use (default 0)\n\n"
+           "DESCRIPTION\n        SPAdes k-mer counting engine (MI355X)\n\n"
+           "        Output: <output_dir>/final_kmers - unordered set of kmers in binary format. Kmers from both forward and\n"
+           "        reverse-complementary reads are taken into account.\n\n"
+           "        Output format: All kmers are written sequentially without any separators. Each kmer takes the same\n"
+           "        number of bits. One kmer of length K takes 2*K bits. Kmers are aligned by 64 bits. Each nucleotide is\n"
+           "        coded with 2 bits: 00 - A, 01 - C, 10 - G, 11 - T.\n",
+           argv0);
+}
+
+int main(int argc, char **argv) {
+    unsigned K = 21, device = 0;
+    std::string workdir, dataset;
+    std::vector<std::string> input;
+    bool help = false, bad = false;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto need = [&](unsigned long long *v) { return i + 1 < argc && parse_uint(argv[++i], v); };
+        unsigned long long v = 0;
+        if (a == "-k" || a == "--kmer") { if (need(&v)) K = (unsigned)v; else bad = true; }
+        else if (a == "-t" || a == "--threads") { if (!need(&v)) bad = true; }
+        else if (a == "-b" || a == "--bufsize") { if (!need(&v)) bad = true; }
+        else if (a == "--device") { if (need(&v)) device = (unsigned)v; else bad = true; }
+        else if (a == "-d" || a == "--dataset") { if (i + 1 < argc) dataset = argv[++i]; else bad = true; }
+        else if (a == "-w" || a == "--workdir") { if (i + 1 < argc) workdir = argv[++i]; else bad = true; }
+        else if (a == "-h" || a == "--help") help = true;
+        else if (!a.empty() && a[0] == '-' && a.size() > 1) bad = true;
+        else input.push_back(a);
+    }
+    if (bad || help) {  // projects/kmercount/main.cpp:169-176
+        usage(argv[0]);
+        return help ? 0 : 1;
+    }
+    if (input.empty() && dataset.empty()) {  // :178-182
+        fprintf(stderr, "ERROR: No input files were specified\n\n");
+        usage(argv[0]);
+        return 255;  // exit(-1)
+    }
+    if (K < 1 || K >= BBK_MAX_K) fatal("k-mer size %u is out of range [1, %d)", K, BBK_MAX_K);
+
+    info("Starting SPAdes k-mer counting engine (MI355X, %s)", bbk_version());
+    info("K-mer length set to %u", K);
+    std::vector<std::string> files = input;
+    if (!dataset.empty()) {
+        files.clear();
+        std::string err;
+        if (!load_dataset_yaml(dataset, files, err)) fatal("%s", err.c_str());
+    }
+    bbk_ctx *ctx = nullptr;
+    check(bbk_ctx_create((int)device, &ctx), "bbk_ctx_create");
+    uint64_t n_reads = 0;
+    bbk_reads *reads = load_reads(ctx, files, &n_reads);
+    bbk_kmerset *set = nullptr;
+    check(bbk_count(ctx, reads, K, BBK_BOTH_STRANDS, &set), "bbk_count");
+    // same line as KMerDiskCounter::Count (common/utils/kmer_mph/kmer_index_builder.hpp:260)
+    info("K-mer counting done. There are %llu kmers in total.", (unsigned long long)bbk_kmerset_size(set));
+    if (!workdir.empty()) mkdir(workdir.c_str(), 0755);
+    const std::string out = (workdir.empty() ? std::string("") : workdir + "/") + "final_kmers";
+    check(bbk_kmerset_write_final_kmers(ctx, set, out.c_str()), "bbk_kmerset_write_final_kmers");
+    info("K-mer counting done, kmers saved to %s", out.c_str());
+    bbk_kmerset_free(set);
+    bbk_reads_free(reads);
+    bbk_ctx_destroy(ctx);
+    return 0;
+}

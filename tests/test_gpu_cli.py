@@ -1,0 +1,62 @@
+"""GPU: the two CLI drop-ins end to end (argv -> files), against the golden md5s and the oracle."""
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+from oracle import oracle as O
+from spades_for_blackbird_amd import build, build_host
+from spades_for_blackbird_amd.tools import gfa_canon
+from tests.helpers import read_fastq_gz
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bins():
+    build.build()
+    return {os.path.basename(p): p for p in build_host.build()}
+
+
+def test_kmercount_cli_toy(bins, golden, golden_dir, tmp_path):
+    g = golden["toy_kmercount"]
+    files = [os.path.join(golden_dir, f) for f in g["files"]]
+    for k, key in ((21, "k21"), (55, "k55")):
+        wd = tmp_path / ("w%d" % k)
+        r = subprocess.run([bins["spades-kmercount"], "-k", str(k), "-t", "4", "-w", str(wd)] + files,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "There are %d kmers in total" % g[key]["n_kmers"] in r.stdout
+        data = open(wd / "final_kmers", "rb").read()
+        assert len(data) == g[key]["bytes"]
+        assert hashlib.md5(data).hexdigest() == g[key]["md5"]
+    # YAML dataset gives the same file
+    y = tmp_path / "toy.yaml"
+    y.write_text("- left reads: [%s]\n  orientation: fr\n  right reads: [%s]\n  type: paired-end\n" % tuple(files))
+    wd = tmp_path / "wy"
+    r = subprocess.run([bins["spades-kmercount"], "-k", "21", "-d", str(y), "-w", str(wd)], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stderr
+    assert hashlib.md5(open(wd / "final_kmers", "rb").read()).hexdigest() == g["k21"]["md5"]
+
+
+def test_gbuilder_cli_toy(bins, golden, golden_dir, tmp_path):
+    g = golden["toy_gbuilder"]
+    f = os.path.join(golden_dir, g["file"])
+    out = tmp_path / "g.gfa"
+    r = subprocess.run([bins["spades-gbuilder"], f, str(out), "-k", "21", "--gfa"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "%d sequences extracted" % g["k21"]["n_unitigs"] in r.stdout
+    txt = open(out).read()
+    S = sorted(l.split("\t")[2] for l in txt.splitlines() if l.startswith("S"))
+    assert hashlib.md5(("\n".join(S) + "\n").encode()).hexdigest() == g["k21"]["sorted_S_sequences_md5"]
+    exp = O.ExtIndex(read_fastq_gz(f), 21, 1).unitigs().gfa()[0]
+    assert gfa_canon.canon_md5(txt) == gfa_canon.canon_md5(exp)
+    assert txt.splitlines()[0].startswith("S\t3\t") and txt.splitlines()[0].endswith("\tDP:f:0\tKC:i:0")
+    out2 = tmp_path / "u.fa"
+    r = subprocess.run([bins["spades-gbuilder"], f, str(out2), "-k", "21"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    fa = open(out2).read()
+    assert fa.startswith(">EDGE_1_length_")
+    assert fa.count(">") == g["k21"]["n_unitigs"]

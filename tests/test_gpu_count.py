@@ -143,3 +143,16 @@ def test_owner_partition(ctx):
             seg = part[off:off + int(c), 0]
             assert np.all(seg[1:] > seg[:-1])
             off += int(c)
+
+
+def test_owner_matches_host_mirror(ctx):
+    """Device owner function == numpy mirror used by the host-side exchange logic."""
+    from spades_for_blackbird_amd import distributed as D
+    reads = synth_reads(300, read_len=100, genome_len=3000, seed=4)
+    for k in (21, 55):
+        s = ctx.count(ctx.reads_from_ascii(reads), k, B.CANONICAL)
+        for nranks in (2, 8):
+            part, counts = s.export_by_owner(nranks)
+            own = D.owner_of(part, nranks)
+            exp = np.repeat(np.arange(nranks), counts.astype(np.int64))
+            assert np.array_equal(own, exp)
