@@ -30,8 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md), the figure fractions are quoted against
-FAMILIES = ["extract", "hist", "scan", "scatter", "unique", "reduce", "expand", "part_hist", "part_scatter",
-            "lds_sort", "compact"]
+FAMILIES = ["extract", "hist", "scan", "scatter", "unique", "reduce", "expand", "part_hist1", "part_scatter1",
+            "part_hist2", "part_scatter2", "lds_dedup", "lds_sort", "compact"]
 
 
 def parse():

@@ -20,8 +20,44 @@
 
 #include "bbk_internal.h"
 #include "kmer_ops.h"
+#include "msd.h"
 
 namespace bbk {
+
+// BBK_DISABLE_MSD=1 forces the LSD path (A/B timing, and tests that cover both paths)
+static bool msd_enabled() {
+    const char *e = getenv("BBK_DISABLE_MSD");
+    return !(e && e[0] == '1');
+}
+
+// Fast path for "distinct + reduce, ascending": hash-partitioned sort-reduce of the raw stream, then
+// a second (small) sort-reduce of the distinct records partitioned on the key bits themselves.
+// Returns false if the MSD path declined; nothing has been written to the outputs then.
+static bool msd_two_stage(bbk_ctx *ctx, unsigned k, const bbk_reads *rd, const void *d_keys, const uint32_t *d_vals,
+                          uint64_t n, bool with_mask, bool want_vals, DevBuf &out_keys, DevBuf &out_vals,
+                          uint64_t &n_distinct, uint64_t &n_instances) {
+    if (!msd_enabled()) return false;
+    const bool in_vals = with_mask || d_vals != nullptr;
+    const int op1 = with_mask ? MSD_OP_OR : (in_vals ? MSD_OP_SUM : (want_vals ? MSD_OP_COUNT : MSD_OP_NONE));
+    MsdOutput a;
+    if (!msd_sort_reduce(ctx, k, MSD_HASH, op1, rd, d_keys, d_vals, n, with_mask, a)) return false;
+    n_instances = a.instances;
+    if (a.n == 0) {
+        out_keys.alloc(16);
+        out_vals.alloc(16);
+        n_distinct = 0;
+        return true;
+    }
+    const bool v = op1 != MSD_OP_NONE;
+    const int op2 = !v ? MSD_OP_NONE : (with_mask ? MSD_OP_OR : MSD_OP_SUM);
+    MsdOutput b;
+    if (!msd_sort_reduce(ctx, k, MSD_KEYS, op2, nullptr, a.keys.p, v ? a.vals.as<uint32_t>() : nullptr, a.n, false, b))
+        return false;
+    out_keys = std::move(b.keys);
+    if (v) out_vals = std::move(b.vals);
+    n_distinct = b.n;
+    return true;
+}
 
 __global__ void k_kmers_per_read(const uint32_t *__restrict__ len, uint64_t n, uint32_t k,
                                  uint64_t *__restrict__ nk) {
@@ -121,6 +157,9 @@ static void launch_expand(bbk_ctx *ctx, const void *in, const uint32_t *cin, uin
         default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %d", (int)(W)); \
     }
 
+uint64_t drop_zero_vals(bbk_ctx *ctx, int W, const void *keys, const uint32_t *vals, uint64_t n, void *out_keys,
+                        uint32_t *out_vals);
+
 // Extract one record per k-mer position, sort, reduce.  Result: distinct canonical keys
 // (ascending) + payload (COUNT: multiplicity; OR: InOutMask).  Shared with extindex.hip.
 void count_canonical(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_mask, bool want_vals, DevBuf &out_keys,
@@ -128,6 +167,21 @@ void count_canonical(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_ma
     const int W = (int)words_of(k);
     n_distinct = 0;
     n_instances = 0;
+    if (msd_two_stage(ctx, k, rd, nullptr, nullptr, 0, with_mask, want_vals, out_keys, out_vals, n_distinct,
+                      n_instances)) {
+        if (with_mask && n_distinct) {
+            // k-mers that never received a bit (reads of length exactly k) are not part of the index
+            DevBuf fk(n_distinct * (size_t)W * 8), fv(n_distinct * 4);
+            const uint64_t kept = drop_zero_vals(ctx, W, out_keys.p, out_vals.as<uint32_t>(), n_distinct, fk.p,
+                                                 fv.as<uint32_t>());
+            if (kept != n_distinct) {
+                out_keys = std::move(fk);
+                out_vals = std::move(fv);
+                n_distinct = kept;
+            }
+        }
+        return;
+    }
     DevBuf koff((rd->n + 1) * sizeof(uint64_t));
     if (rd->n) {
         hipLaunchKernelGGL(k_kmers_per_read, dim3((unsigned)((rd->n + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -196,6 +250,16 @@ static void expand_both_strands(bbk_ctx *ctx, unsigned k, const DevBuf &ck, cons
     }
     BBK_DISPATCH_W(W, launch_expand<W_>(ctx, ck.p, wc ? cv->as<uint32_t>() : nullptr, D, (int)k, e.p,
                                         wc ? ec.as<uint32_t>() : nullptr));
+    if (msd_enabled()) {
+        MsdOutput m;
+        if (msd_sort_reduce(ctx, k, MSD_KEYS, wc ? MSD_OP_SUM : MSD_OP_NONE, nullptr, e.p,
+                            wc ? ec.as<uint32_t>() : nullptr, 2 * D, false, m)) {
+            s.n = m.n;
+            s.keys = std::move(m.keys);
+            if (wc) s.counts = std::move(m.vals);
+            return;
+        }
+    }
     sort_records(ctx, W, e.p, et.p, wc ? ec.as<uint32_t>() : nullptr, wc ? ect.as<uint32_t>() : nullptr, 2 * D,
                  key_passes(k));
     const uint64_t D2 = unique_records(ctx, W, e.p, wc ? ec.as<uint32_t>() : nullptr, 2 * D, et.p,
@@ -238,6 +302,17 @@ int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, 
         s->has_counts = wc;
         DevBuf ck, cv;
         uint64_t D = 0, N = 0;
+        if (both && msd_enabled()) {
+            // fast path: hash-partitioned dedup of the canonical stream, then expand and sort once
+            MsdOutput a;
+            if (msd_sort_reduce(ctx, k, MSD_HASH, wc ? MSD_OP_COUNT : MSD_OP_NONE, reads, nullptr, nullptr, 0, false,
+                                a)) {
+                s->instances = 2 * a.instances;
+                expand_both_strands(ctx, k, a.keys, wc ? &a.vals : nullptr, a.n, *s);
+                *out = s.release();
+                return;
+            }
+        }
         count_canonical(ctx, reads, k, /*with_mask=*/false, wc, ck, cv, D, N);
         s->instances = both ? 2 * N : N;
         if (canon) {
@@ -268,6 +343,17 @@ int bbk_kmerset_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_coun
             if (d_counts) s->counts.alloc(16);
             *out = s.release();
             return;
+        }
+        if (msd_enabled()) {
+            MsdOutput m;
+            if (msd_sort_reduce(ctx, k, MSD_KEYS, d_counts ? MSD_OP_SUM : MSD_OP_NONE, nullptr, d_keys,
+                                (const uint32_t *)d_counts, n, false, m)) {
+                s->n = m.n;
+                s->keys = std::move(m.keys);
+                if (d_counts) s->counts = std::move(m.vals);
+                *out = s.release();
+                return;
+            }
         }
         DevBuf a(n * rec), b(n * rec), ca, cb;
         BBK_HIP(hipMemcpyAsync(a.p, d_keys, n * rec, hipMemcpyDeviceToDevice, ctx->stream));

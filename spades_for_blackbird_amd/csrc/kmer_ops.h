@@ -84,6 +84,45 @@ __device__ inline Key<W> kmer_extract(const uint64_t *__restrict__ rw, uint32_t 
     return r;
 }
 
+// 8-byte keys (k <= 32): branch-free extraction (two unconditional word loads, the second clamped to
+// the read's last word) and one-reversal canonicalisation.  With R = rev2(fwd) (the k-mer read
+// backwards, left aligned) the reverse complement is (~R) >> (64-2k), and comparing fwd with it in
+// base order (rtseq.hpp:407-415) is comparing R with (~fwd) << (64-2k) numerically.
+__device__ inline Key<1> kmer_extract_canon1(const uint64_t *__restrict__ rw, uint32_t p, int k, uint32_t last_word,
+                                             bool *minimal) {
+    const uint32_t wi = p >> 5;
+    const uint32_t sh = (p & 31u) << 1;
+    const uint64_t lo = rw[wi];
+    const uint64_t hi = rw[wi + 1 <= last_word ? wi + 1 : last_word];
+    uint64_t fwd = (lo >> sh) | ((hi << 1) << (63u - sh));
+    const uint32_t pad = 64u - 2u * (uint32_t)k;
+    fwd = (fwd << pad) >> pad;
+    const uint64_t R = rev2(fwd);
+    const uint64_t C = (~fwd) << pad;
+    *minimal = R <= C;
+    Key<1> o;
+    o.w[0] = *minimal ? fwd : ((~R) >> pad);
+    return o;
+}
+
+// cheap 32-bit mixing hash for the partition levels (three 32-bit multiplies; the 64-bit
+// splitmix of owner_mix costs ~4x more on this hardware and only ~20 top bits are consumed)
+template <int W>
+__device__ inline uint32_t part_hash32(const Key<W> &key) {
+    uint32_t h = 0x9E3779B9u;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        h ^= (uint32_t)key.w[i];
+        h *= 0x85EBCA6Bu;
+        h ^= h >> 15;
+        h += (uint32_t)(key.w[i] >> 32) * 0xC2B2AE35u;
+        h ^= h >> 13;
+    }
+    h *= 0x27D4EB2Fu;
+    h ^= h >> 16;
+    return h;
+}
+
 __device__ inline uint32_t base_at(const uint64_t *__restrict__ rw, uint32_t p) {
     return (uint32_t)((rw[p >> 5] >> ((p & 31u) << 1)) & 3ull);
 }

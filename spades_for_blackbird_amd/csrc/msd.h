@@ -1,0 +1,28 @@
+// msd.h -- interface of the MSD-partition + in-LDS sort path (msd.hip).
+#pragma once
+
+#include "bbk_internal.h"
+
+namespace bbk {
+
+enum { MSD_HASH = 0, MSD_KEYS = 1, MSD_REF = 2 };                      // partition prefix
+enum { MSD_OP_NONE = 0, MSD_OP_COUNT = 1, MSD_OP_SUM = 2, MSD_OP_OR = 3 };  // per-key reduction
+
+struct MsdOutput {
+    DevBuf keys;        // distinct records: bucket-major in prefix order, ascending inside a bucket
+    DevBuf vals;        // reduced payload (op != NONE)
+    DevBuf bucket_off;  // nbuckets + 1 offsets into keys
+    uint64_t n = 0;
+    uint64_t instances = 0;
+    uint64_t overflow_buckets = 0;
+    uint32_t nbuckets = 0;
+};
+
+// Sort + reduce records that come either from reads (rd != null: canonical k-mers are extracted on
+// the fly, with_mask adds the InOutMask bits of every occurrence as payload) or from a key array
+// (d_keys[, d_vals], n).  Returns false when this path declines (key width, size, too much
+// overflow): the caller then uses the LSD path.  MSD_KEYS output is globally ascending.
+bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_reads *rd, const void *d_keys,
+                     const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out);
+
+}  // namespace bbk

@@ -1,0 +1,1035 @@
+// msd.hip -- the fast sort-and-count path: two MSD radix-partition levels in HBM, then one
+// workgroup per bucket sorts + reduces its keys entirely in LDS.
+//
+// Why: the LSD path (primitives.hip) moves every record 3x per 8-bit pass (k=21: 6 passes, ~19 N*W
+// bytes).  Here a record is written by the (fused) extraction+partition, read and written once
+// more by the second partition level and read once by the bucket kernel: ~5 N*W bytes, independent
+// of the key length, and the duplicate-heavy k-mer stream (50x coverage) collapses inside LDS.
+//
+//   k_part_hist  : digit histogram of a level (from reads: k-mers are re-extracted, nothing is
+//                  stored; from keys: one coalesced read)                       [LDS ds_add]
+//   k_part       : LDS histogram with returning ds_add = local rank, one global atomicAdd per
+//                  (tile, non-empty bin) reserves the output run, keys reordered in LDS so that a
+//                  wave stores contiguous per-bin runs (unstable: the buckets get sorted later)
+//   k_bucket     : <= CAP keys of one bucket in LDS; LSD radix sort over the key bits with 64-wide
+//                  ballot match-any ranking; head flags + segmented reduce (count / sum / OR);
+//                  distinct records written back in place, count per bucket
+//   k_compact    : buckets -> dense output
+//
+// The partition digit comes from a 64-bit "prefix" p(key): HASH (mix64: uniform whatever the
+// sequence composition; used when only the distinct set matters), KEYS (the key's own top bits:
+// output globally ascending) or REF (XXH3 bucket of 16, then key bits: the final_kmers order,
+// reference kmer_buckets.hpp:28-33 + kmer_index_builder.hpp:168-181).  Level 2 maps the
+// remaining prefix bits monotonically onto nb2 bins, so bucket order == prefix order.
+// Buckets larger than CAP (a k-mer repeated thousands of times, skewed composition in KEYS mode)
+// are finished by the LSD path, per bucket; if too much overflows the caller falls back entirely.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "bbk_internal.h"
+#include "kmer_ops.h"
+#include "msd.h"
+
+namespace bbk {
+
+// Partition tile: 8192 records of 8 B (4096 of 16 B) staged in LDS.  From a key array 512 threads x 16
+// items keep the loads wide; from reads (extraction fused: instruction- and latency-bound) the same
+// tile is spread over 1024 threads x 8 items so that a CU holds 16 waves at one workgroup per CU.
+constexpr int part_threads(int src) { return src == 1 ? 1024 : 512; }
+template <int W, int SRC>
+struct PartCfg {
+    static constexpr int TILE = (W == 1) ? 8192 : 4096;
+    static constexpr int THREADS = part_threads(SRC);
+    static constexpr int ITEMS = TILE / THREADS;
+};
+constexpr int kMaxBins = 1024;
+constexpr int kBktThreads = 256;
+constexpr int kBktWaves = kBktThreads / 64;
+
+// 32-bit partition prefix: bucket order == prefix order (only ~20 top bits are ever consumed)
+template <int W>
+__device__ inline uint32_t prefix_of(const Key<W> &key, int dmode, int w0bits) {
+    if (dmode == MSD_HASH) return part_hash32<W>(key);
+    const uint64_t top = (w0bits >= 64) ? key.w[0] : (key.w[0] << (64 - w0bits));
+    if (dmode == MSD_KEYS) return (uint32_t)(top >> 32);
+    const uint32_t b = (uint32_t)__umul64hi(xxh3_64<W>(key), 16ull);
+    return (b << 28) | (uint32_t)(top >> 36);
+}
+
+struct PartLevel {
+    int level;        // 1 or 2
+    int b1;           // log2(nb1)
+    uint32_t nb1;
+    int dmode;
+    int w0bits;
+    // level 2: every level-1 segment gets its own bin count (sized from its record count, so a
+    // skewed prefix distribution still gives buckets of the target size) and flat bin base
+    const uint32_t *seg_nb2;
+    const uint32_t *seg_bin_start;
+};
+
+// bin of this level inside its segment (nb = bins of the segment at level 2)
+__device__ inline uint32_t bin_of(uint32_t p, const PartLevel &L, uint32_t nb) {
+    if (L.level == 1) return L.b1 == 0 ? 0u : (p >> (32 - L.b1));
+    const uint32_t rest = L.b1 == 0 ? p : (p << L.b1);
+    return __umulhi(rest, nb);
+}
+
+struct ReadSrc {
+    const uint64_t *words;
+    const uint64_t *woff;
+    const uint32_t *len;
+    const uint64_t *koff;       // exclusive scan of k-mers per read (n_reads + 1)
+    const uint32_t *tile_read;  // first read of every tile
+    uint64_t n_reads;
+    int k;
+};
+
+// record j of the instance space -> canonical key (+ InOutMask bits).  `rl` is the caller's running
+// read cursor (index into s_koff): instances are visited in increasing order by a lane, so the read
+// is found by a short linear advance instead of a binary search per record.
+// s_rel[i] = koff[r0 + i] - koff[r0] (u32: a batch holds < 2^32 records), jr = j - koff[r0]
+template <int W, bool WITH_MASK>
+__device__ inline void read_record(const ReadSrc &S, uint32_t jr, const uint32_t *s_rel, uint32_t r0, uint32_t nr,
+                                   uint32_t &rl, Key<W> &key, uint32_t &val) {
+    while (rl + 1 < nr && s_rel[rl + 1] <= jr) ++rl;
+    const uint64_t r = (uint64_t)r0 + rl;
+    const uint32_t p = jr - s_rel[rl];
+    const uint64_t *rw = S.words + S.woff[r];
+    bool minimal;
+    if constexpr (W == 1) {
+        // the record exists, so the read holds at least p + k bases: its last word index follows
+        const uint32_t last_word = (S.len[r] - 1u) >> 5;
+        key = kmer_extract_canon1(rw, p, S.k, last_word, &minimal);
+    } else {
+        const Key<W> fwd = kmer_extract<W>(rw, p, S.k);
+        const Key<W> rc = kmer_rc<W>(fwd, S.k);
+        minimal = !kmer_less_nucl<W>(rc, fwd);
+        key = key_select<W>(minimal, fwd, rc);
+    }
+    if (WITH_MASK) {
+        const uint32_t L = S.len[r];
+        uint32_t m = 0;
+        if (p + (uint32_t)S.k < L) {
+            const uint32_t c = base_at(rw, p + (uint32_t)S.k);
+            m |= 1u << (minimal ? c : 7u - c);
+        }
+        if (p >= 1) {
+            const uint32_t c = base_at(rw, p - 1);
+            m |= 1u << (minimal ? 4u + c : 3u - c);
+        }
+        val = m;
+    }
+}
+
+// largest r in [0, nr) with s_rel[r] <= jr
+__device__ inline uint32_t read_of(const uint32_t *s_rel, uint32_t nr, uint32_t jr) {
+    uint32_t lo = 0, hi = nr;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_rel[mid] <= jr) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+
+// first read of every tile of the instance space
+__global__ void k_tile_reads(const uint64_t *__restrict__ koff, uint64_t n_reads, uint64_t n_tiles, uint32_t tile,
+                             uint32_t *__restrict__ tile_read) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    const uint64_t j = t * (uint64_t)tile;
+    // largest r with koff[r] <= j (koff[n_reads] = N)
+    uint64_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (koff[mid] <= j) lo = mid;
+        else hi = mid;
+    }
+    tile_read[t] = (uint32_t)lo;
+}
+
+// Tile -> (segment, range).  Level 1: tile t covers records [t*TILE, ...).  Level 2: tiles never
+// straddle a level-1 bin: seg_tile_start[b] = first tile of bin b (nb1 + 1 entries).
+struct TileMap {
+    const uint32_t *seg_tile_start;  // null for level 1
+    const uint32_t *seg_off;         // record offset of every level-1 bin (nb1 + 1), level 2 only
+    uint32_t nseg;
+    uint64_t n;
+};
+
+__device__ inline void tile_range(const TileMap &M, uint32_t tile, uint32_t kPartTile, uint32_t *seg, uint64_t *begin,
+                                  uint32_t *count) {
+    if (!M.seg_tile_start) {
+        *seg = 0;
+        *begin = (uint64_t)tile * kPartTile;
+        const uint64_t rem = M.n - *begin;
+        *count = rem < (uint64_t)kPartTile ? (uint32_t)rem : (uint32_t)kPartTile;
+        return;
+    }
+    uint32_t lo = 0, hi = M.nseg;  // largest s with seg_tile_start[s] <= tile
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (M.seg_tile_start[mid] <= tile) lo = mid;
+        else hi = mid;
+    }
+    *seg = lo;
+    const uint64_t b = (uint64_t)M.seg_off[lo] + (uint64_t)(tile - M.seg_tile_start[lo]) * kPartTile;
+    const uint64_t e = M.seg_off[lo + 1];
+    *begin = b;
+    *count = (e - b) < (uint64_t)kPartTile ? (uint32_t)(e - b) : (uint32_t)kPartTile;
+}
+
+// SRC 0: key array, SRC 1: reads.  HIST_ONLY: accumulate the level histogram; else scatter.
+template <int W, int SRC, bool HAS_VAL, bool HIST_ONLY>
+__global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__restrict__ in, const uint32_t *__restrict__ vin,
+                                                      ReadSrc S, TileMap M, PartLevel L,
+                                                      uint32_t *__restrict__ ghist,    // HIST_ONLY: [nseg * nb]
+                                                      uint32_t *__restrict__ cursor,   // scatter: [nseg * nb] running offsets
+                                                      Key<W> *__restrict__ out, uint32_t *__restrict__ vout) {
+    constexpr int kPartItems = PartCfg<W, SRC>::ITEMS, kPartTile = PartCfg<W, SRC>::TILE,
+                  kPartThreads = PartCfg<W, SRC>::THREADS;
+    constexpr int kKoffSlots = kPartTile + 8;  // a tile spans at most TILE + 1 reads (every read has >= 1 record... or 0)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: lhist[kMaxBins] | lstart[kMaxBins] | goff[kMaxBins] | scan[32] | rel[kKoffSlots] (SRC 1) | stage | vstage
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *lstart = lhist + kMaxBins;
+    uint32_t *goff = lstart + kMaxBins;
+    uint32_t *scan_tmp = goff + kMaxBins;
+    uint32_t *s_rel = scan_tmp + 32;
+    unsigned char *after = reinterpret_cast<unsigned char *>(s_rel) + (SRC == 1 ? sizeof(uint32_t) * kKoffSlots : 0);
+    Key<W> *stage = reinterpret_cast<Key<W> *>(after);
+    uint32_t *vstage = reinterpret_cast<uint32_t *>(after + sizeof(Key<W>) * kPartTile);
+
+    const int tid = threadIdx.x;
+    uint32_t seg, count;
+    uint64_t begin;
+    tile_range(M, blockIdx.x, (uint32_t)kPartTile, &seg, &begin, &count);
+    const uint32_t nb = (L.level == 1) ? L.nb1 : L.seg_nb2[seg];
+    const uint64_t gbin0 = (L.level == 1) ? 0ull : (uint64_t)L.seg_bin_start[seg];  // flat index of bin 0
+
+    for (uint32_t b = tid; b < nb; b += kPartThreads) lhist[b] = 0;
+    uint32_t r0 = 0, nr = 0;
+    uint64_t k0 = 0;  // koff of the tile's first read
+    if (SRC == 1) {
+        r0 = S.tile_read[blockIdx.x];
+        const uint32_t r1 = S.tile_read[blockIdx.x + 1];
+        nr = r1 - r0 + 1;  // reads r0..r1 inclusive
+        if (nr > (uint32_t)kKoffSlots - 1) nr = kKoffSlots - 1;  // cannot happen: reads without k-mers own no record
+        k0 = S.koff[r0];
+        for (uint32_t i = tid; i <= nr; i += kPartThreads)
+            s_rel[i] = (r0 + i <= S.n_reads) ? (uint32_t)(S.koff[r0 + i] - k0) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+
+    Key<W> keys[kPartItems];
+    uint32_t vals[kPartItems];
+    uint32_t binrank[kPartItems];  // bin << 16 | rank (rank < 8192 fits 13 bits; bins < 1024)
+    // record owned by (item i, this thread).  Key arrays are read striped over the block (coalesced
+    // 8/16-byte loads); reads are walked wave-contiguously: a wave covers 64 consecutive k-mer
+    // positions per item (they share the read's words in cache) and every lane's record index only
+    // grows, so the read cursor advances linearly.
+    const int lane_ = tid & 63, wave_ = tid >> 6;
+    const uint32_t jbase = (uint32_t)(begin - k0);  // SRC 1: tile start relative to its first read
+    uint32_t rl = 0;
+    if (SRC == 1) {
+        const uint32_t first = (uint32_t)(wave_ * (kPartItems * 64));
+        if (first < count) rl = read_of(s_rel, nr, jbase + first);
+    }
+#pragma unroll
+    for (int i = 0; i < kPartItems; ++i) {
+        const uint32_t local = (SRC == 1) ? (uint32_t)(wave_ * (kPartItems * 64) + i * 64 + lane_)
+                                          : (uint32_t)(i * kPartThreads + tid);
+        const bool valid = local < count;
+#pragma unroll
+        for (int w = 0; w < W; ++w) keys[i].w[w] = 0;
+        vals[i] = 0;
+        binrank[i] = 0xFFFFFFFFu;
+        if (valid) {
+            if (SRC == 0) {
+                keys[i] = key_load<W>(&in[begin + local]);
+                if (HAS_VAL) vals[i] = vin[begin + local];
+            } else {
+                read_record<W, HAS_VAL>(S, jbase + local, s_rel, r0, nr, rl, keys[i], vals[i]);
+            }
+            const uint32_t b = bin_of(prefix_of<W>(keys[i], L.dmode, L.w0bits), L, nb);
+            const uint32_t rank = atomicAdd(&lhist[b], 1u);
+            binrank[i] = (b << 16) | rank;
+        }
+    }
+    __syncthreads();
+
+    if (HIST_ONLY) {
+        for (uint32_t b = tid; b < nb; b += kPartThreads) {
+            const uint32_t c = lhist[b];
+            if (c) atomicAdd(&ghist[gbin0 + b], c);
+        }
+        return;
+    }
+
+    // exclusive scan of the local histogram (<= 1024 bins; BPT bins per thread)
+    {
+        constexpr int BPT = kMaxBins / kPartThreads;  // 2 (512 threads) or 1 (1024 threads)
+        uint32_t c[BPT];
+        uint32_t v = 0;
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) {
+            const uint32_t bq = BPT * tid + q;
+            c[q] = bq < nb ? lhist[bq] : 0;
+            v += c[q];
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) scan_tmp[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += scan_tmp[w];
+        uint32_t ex = wbase + incl - v;
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) {
+            const uint32_t bq = BPT * tid + q;
+            if (bq < nb) {
+                lstart[bq] = ex;
+                goff[bq] = (c[q] ? atomicAdd(&cursor[gbin0 + bq], c[q]) : 0u) - ex;
+            }
+            ex += c[q];
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < kPartItems; ++i) {
+        if (binrank[i] != 0xFFFFFFFFu) {
+            const uint32_t pos = lstart[binrank[i] >> 16] + (binrank[i] & 0xFFFFu);
+            key_store<W>(&stage[pos], keys[i]);
+            if (HAS_VAL) vstage[pos] = vals[i];
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < kPartItems; ++i) {
+        const uint32_t pos = (uint32_t)(i * kPartThreads + tid);
+        if (pos < count) {
+            const Key<W> key = key_load<W>(&stage[pos]);
+            const uint32_t b = bin_of(prefix_of<W>(key, L.dmode, L.w0bits), L, nb);
+            const uint32_t g = goff[b] + pos;
+            key_store<W>(&out[g], key);
+            if (HAS_VAL) vout[g] = vstage[pos];
+        }
+    }
+}
+
+static size_t part_smem(int W, int tile, int src, bool has_val, bool hist_only) {
+    size_t s = sizeof(uint32_t) * (3 * kMaxBins + 32) + (src == 1 ? sizeof(uint32_t) * ((size_t)tile + 8) : 0);
+    if (!hist_only) s += (size_t)W * 8 * tile + (has_val ? 4 * (size_t)tile : 0);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// bucket kernel
+// ------------------------------------------------------------------------------------------
+__device__ inline uint64_t match8(uint32_t d, bool valid) {
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+struct BucketArgs {
+    const uint32_t *boff;        // nbuckets + 1 record offsets
+    uint32_t *dcount;            // distinct per bucket; 0xFFFFFFFF = overflow (left untouched)
+    const uint32_t *bucket_ids;  // null: bucket = blockIdx.x; else the list of buckets to process
+    int k;
+};
+
+// OP: 0 unique only, 1 COUNT (run length), 2 SUM of vals, 3 OR of vals.  NT threads, CAP = NT * ITEMS.
+template <int W, int NT, int ITEMS, int OP>
+__global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_t *__restrict__ vals, BucketArgs A) {
+    constexpr int CAP = NT * ITEMS;
+    constexpr int NWAVES = NT / 64;
+    constexpr bool IN_VAL = OP >= 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: wave_cnt[NWAVES][256] | dstart[256] | scan[32] | skeys[CAP] | svals[CAP] (IN_VAL)
+    uint32_t(*wave_cnt)[256] = reinterpret_cast<uint32_t(*)[256]>(smem);
+    uint32_t *dstart = reinterpret_cast<uint32_t *>(smem) + NWAVES * 256;
+    uint32_t *scan_tmp = dstart + 256;
+    Key<W> *skeys = reinterpret_cast<Key<W> *>(scan_tmp + 32);
+    uint32_t *svals = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(skeys) + sizeof(Key<W>) * CAP);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = A.bucket_ids ? A.bucket_ids[blockIdx.x] : blockIdx.x;
+    const uint32_t start = A.boff[b];
+    const uint32_t n = A.boff[b + 1] - start;
+    if (n == 0) {
+        if (tid == 0) A.dcount[b] = 0;
+        return;
+    }
+    if (n > (uint32_t)CAP) {
+        if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t p = (uint32_t)(i * NT + tid);
+        if (p < n) {
+            key_store<W>(&skeys[p], key_load<W>(&buf[start + p]));
+            if (IN_VAL) svals[p] = vals[start + p];
+        }
+    }
+    __syncthreads();
+
+    // ---- LSD radix sort over the populated key bits (last word first: word 0 is most significant)
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int lastbits = 2 * A.k - 64 * (W - 1);
+    for (int w = W - 1; w >= 0; --w) {
+        const int wbits = (w == W - 1) ? lastbits : 64;
+        for (int shift = 0; shift < wbits; shift += 8) {
+            Key<W> keys[ITEMS];
+            uint32_t v[ITEMS];
+            uint32_t dr[ITEMS];  // digit << 16 | rank-in-wave
+            if (tid < 256) {
+#pragma unroll
+                for (int j = 0; j < NWAVES; ++j) wave_cnt[j][tid] = 0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const uint32_t p = (uint32_t)(wave * (ITEMS * 64) + i * 64 + lane);
+                const bool valid = p < n;
+                uint32_t d = 0;
+#pragma unroll
+                for (int j = 0; j < W; ++j) keys[i].w[j] = 0;
+                v[i] = 0;
+                if (valid) {
+                    keys[i] = key_load<W>(&skeys[p]);
+                    if (IN_VAL) v[i] = svals[p];
+                    const uint64_t word = (W == 1) ? keys[i].w[0] : reinterpret_cast<const uint64_t *>(&skeys[p])[w];
+                    d = (uint32_t)(word >> shift) & 0xFFu;
+                }
+                const uint64_t peers = match8(d, valid);
+                const uint32_t pre = wave_cnt[wave][d];
+                dr[i] = (d << 16) | (pre + (uint32_t)__popcll(peers & lt_mask));
+                if (valid && (peers >> lane) == 1ull) wave_cnt[wave][d] = pre + (uint32_t)__popcll(peers);
+            }
+            __syncthreads();
+            {
+                uint32_t tot = 0, incl = 0;
+                if (tid < 256) {
+#pragma unroll
+                    for (int j = 0; j < NWAVES; ++j) {
+                        const uint32_t c = wave_cnt[j][tid];
+                        wave_cnt[j][tid] = tot;
+                        tot += c;
+                    }
+                    incl = tot;
+#pragma unroll
+                    for (int dd = 1; dd < 64; dd <<= 1) {
+                        uint32_t t = __shfl_up(incl, dd, 64);
+                        if (lane >= dd) incl += t;
+                    }
+                    if (lane == 63) scan_tmp[wave] = incl;
+                }
+                __syncthreads();
+                if (tid < 256) {
+                    uint32_t wbase = 0;
+                    for (int j = 0; j < wave; ++j) wbase += scan_tmp[j];
+                    dstart[tid] = wbase + incl - tot;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const uint32_t p = (uint32_t)(wave * (ITEMS * 64) + i * 64 + lane);
+                if (p < n) {
+                    const uint32_t d = dr[i] >> 16;
+                    const uint32_t pos = dstart[d] + wave_cnt[wave][d] + (dr[i] & 0xFFFFu);
+                    key_store<W>(&skeys[pos], keys[i]);
+                    if (IN_VAL) svals[pos] = v[i];
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- heads + segmented reduce; blocked ownership: thread t owns [t*ITEMS, (t+1)*ITEMS)
+    Key<W> mine[ITEMS];
+    uint32_t mv[ITEMS];
+    const uint32_t p0 = (uint32_t)tid * ITEMS;
+    Key<W> prev;
+#pragma unroll
+    for (int j = 0; j < W; ++j) prev.w[j] = ~0ull;  // cannot equal a real key: unused high bits are 0
+    if (p0 > 0 && p0 - 1 < n) prev = key_load<W>(&skeys[p0 - 1]);
+    uint32_t nheads = 0;
+    uint32_t headbits = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) mine[i].w[j] = 0;
+        mv[i] = 0;
+        if (p0 + i < n) {
+            mine[i] = key_load<W>(&skeys[p0 + i]);
+            if (IN_VAL) mv[i] = svals[p0 + i];
+            const bool h = (i == 0) ? !key_eq<W>(mine[0], prev) : !key_eq<W>(mine[i], mine[i - 1]);
+            if (h) {
+                headbits |= 1u << i;
+                ++nheads;
+            }
+        }
+    }
+    uint32_t excl, total;
+    {
+        uint32_t incl = nheads;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            uint32_t t = __shfl_up(incl, dd, 64);
+            if (lane >= dd) incl += t;
+        }
+        __syncthreads();  // everyone has its keys in registers: skeys may be reused below
+        if (lane == 63) scan_tmp[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+        for (int j = 0; j < NWAVES; ++j) {
+            if (j < wave) wbase += scan_tmp[j];
+            tot += scan_tmp[j];
+        }
+        excl = wbase + incl - nheads;
+        total = tot;
+    }
+    uint32_t *acc = reinterpret_cast<uint32_t *>(skeys);  // CAP u32 fit in the key buffer
+    if (OP != 0) {
+        for (uint32_t s = tid; s < total; s += NT) acc[s] = 0;
+        __syncthreads();
+    }
+    {
+        int seg = (int)excl - 1;  // segment of the records before my first head
+        uint32_t a = 0;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            if (p0 + i < n) {
+                if (headbits & (1u << i)) {
+                    if (OP != 0 && any) {
+                        if (OP == 3) atomicOr(&acc[seg], a);
+                        else atomicAdd(&acc[seg], a);
+                    }
+                    ++seg;
+                    a = 0;
+                    key_store<W>(&buf[start + (uint32_t)seg], mine[i]);  // distinct keys, in place
+                }
+                any = true;
+                if (OP == 1) a += 1;
+                else if (OP == 2) a += mv[i];
+                else if (OP == 3) a |= mv[i];
+            }
+        }
+        if (OP != 0 && any) {
+            if (OP == 3) atomicOr(&acc[seg], a);
+            else atomicAdd(&acc[seg], a);
+        }
+    }
+    if (OP != 0) {
+        __syncthreads();
+        for (uint32_t s = tid; s < total; s += NT) vals[start + s] = acc[s];
+    }
+    if (tid == 0) A.dcount[b] = total;
+}
+
+template <int W, int NT, int ITEMS, int OP>
+static size_t bucket_smem() {
+    return sizeof(uint32_t) * ((NT / 64) * 256 + 256 + 32) + (size_t)W * 8 * NT * ITEMS + (OP >= 2 ? 4 * NT * ITEMS : 0);
+}
+
+// ---- dedup by an LDS hash table (8-byte keys): when the caller only needs the distinct set (the
+// hash-partitioned first stage: a second stage sorts the survivors anyway) the bucket does not have
+// to be sorted.  Records are streamed from HBM straight into an open-addressing table with 64-bit
+// ds_cmpst; with 50x coverage ~8 of 9 records find their key already there on the first probe.
+// ~30 instructions per record instead of 6 radix passes.  The distinct keys (+ reduced payload)
+// are written back in place in table order.
+constexpr int kHashThreads = 512;
+constexpr int kHashItems = 12;                      // 512 x 12 = 6144 = kBucketCap
+constexpr uint32_t kHashSlots = 8192;               // load factor <= 0.75 even if every record is distinct
+
+template <int OP>
+__global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict__ buf, uint32_t *__restrict__ vals,
+                                                             BucketArgs A) {
+    constexpr bool IN_VAL = OP >= 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *tab = reinterpret_cast<unsigned long long *>(smem);
+    uint32_t *pay = reinterpret_cast<uint32_t *>(smem + sizeof(unsigned long long) * kHashSlots);
+    uint32_t *scan_tmp = pay + (OP != 0 ? kHashSlots : 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = A.bucket_ids ? A.bucket_ids[blockIdx.x] : blockIdx.x;
+    const uint32_t start = A.boff[b];
+    const uint32_t n = A.boff[b + 1] - start;
+    if (n == 0) {
+        if (tid == 0) A.dcount[b] = 0;
+        return;
+    }
+    if (n > (uint32_t)(kHashThreads * kHashItems)) {
+        if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
+        return;
+    }
+    constexpr unsigned long long EMPTY = ~0ull;
+    for (uint32_t s = tid; s < kHashSlots; s += kHashThreads) {
+        tab[s] = EMPTY;
+        if (OP != 0) pay[s] = 0;
+    }
+    __syncthreads();
+    uint64_t kk[kHashItems];
+    uint32_t vv[kHashItems];
+#pragma unroll
+    for (int i = 0; i < kHashItems; ++i) {  // all loads first: independent, in flight together
+        const uint32_t p = (uint32_t)(i * kHashThreads + tid);
+        kk[i] = EMPTY;
+        vv[i] = 0;
+        if (p < n) {
+            kk[i] = buf[start + p].w[0];
+            if (IN_VAL) vv[i] = vals[start + p];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kHashItems; ++i) {
+        if (kk[i] != EMPTY) {
+            uint64_t h = kk[i] * 0x9E3779B97F4A7C15ull;
+            h ^= h >> 29;
+            uint32_t slot = (uint32_t)(h * 0xBF58476D1CE4E5B9ull >> 40) & (kHashSlots - 1);
+            for (;;) {
+                const unsigned long long old = atomicCAS(&tab[slot], EMPTY, (unsigned long long)kk[i]);
+                if (old == EMPTY || old == kk[i]) break;
+                slot = (slot + 1) & (kHashSlots - 1);
+            }
+            if (OP == 1) atomicAdd(&pay[slot], 1u);
+            else if (OP == 2) atomicAdd(&pay[slot], vv[i]);
+            else if (OP == 3) atomicOr(&pay[slot], vv[i]);
+        }
+    }
+    __syncthreads();
+    // compaction of the occupied slots: thread t owns slots [t*16, t*16+16)
+    constexpr int SPT = kHashSlots / kHashThreads;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) cnt += tab[tid * SPT + j] != EMPTY ? 1u : 0u;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        uint32_t t = __shfl_up(incl, dd, 64);
+        if (lane >= dd) incl += t;
+    }
+    if (lane == 63) scan_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (int j = 0; j < kHashThreads / 64; ++j) {
+        if (j < wave) wbase += scan_tmp[j];
+        total += scan_tmp[j];
+    }
+    uint32_t o = start + wbase + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+        const unsigned long long key = tab[tid * SPT + j];
+        if (key != EMPTY) {
+            buf[o].w[0] = key;
+            if (OP != 0) vals[o] = pay[tid * SPT + j];
+            ++o;
+        }
+    }
+    if (tid == 0) A.dcount[b] = total;
+}
+
+template <int OP>
+static size_t bucket_hash_smem() {
+    return sizeof(unsigned long long) * kHashSlots + (OP != 0 ? 4 * kHashSlots : 0) + 64;
+}
+
+// one wave per bucket: dense output
+template <int W, bool HAS_VAL>
+__global__ __launch_bounds__(256) void k_compact(const Key<W> *__restrict__ buf, const uint32_t *__restrict__ vals,
+                                                const uint32_t *__restrict__ boff, const uint32_t *__restrict__ dcount,
+                                                const uint64_t *__restrict__ doff, uint32_t nbuckets,
+                                                Key<W> *__restrict__ out, uint32_t *__restrict__ vout) {
+    const uint32_t b = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (b >= nbuckets) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t c = dcount[b];
+    const uint32_t s = boff[b];
+    const uint64_t d = doff[b];
+    for (uint32_t i = lane; i < c; i += 64) {
+        key_store<W>(&out[d + i], key_load<W>(&buf[s + i]));
+        if (HAS_VAL) vout[d + i] = vals[s + i];
+    }
+}
+
+__global__ void k_u32_to_u64(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out, uint32_t clampv) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] == 0xFFFFFFFFu ? (uint64_t)clampv : (uint64_t)in[i];
+}
+
+__global__ void k_scan_to_u32(const uint64_t *__restrict__ in, uint64_t n, uint64_t total, uint32_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)in[i];
+    if (i == n) out[n] = (uint32_t)total;
+}
+
+__global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, uint64_t n, uint32_t k, uint64_t *__restrict__ nk) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t L = len[i];
+        nk[i] = L >= k ? (uint64_t)(L - k + 1) : 0ull;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------
+constexpr int kBucketItems = 24;                            // CAP = 6144 records (256 threads)
+constexpr uint32_t kBucketCap = kBktThreads * kBucketItems;
+constexpr uint32_t kBucketCapBig = 2 * kBucketCap;          // second chance with 512 threads: 12288 records
+// mean bucket = 0.70 CAP: a bucket holds ~100 distinct genomic k-mers x their multiplicity (~40 at 50x
+// coverage), so its size varies far more than Poisson on the record count would suggest
+constexpr double kBucketFill = 0.70;
+
+template <int W>
+struct MsdRunner {
+    bbk_ctx *ctx;
+    unsigned k;
+    int dmode;
+    int op;        // MSD_OP_*
+    bool in_vals;  // records carry a payload from the start (mask extraction or input counts)
+
+    template <int SRC, bool HAS_VAL, bool HIST>
+    void launch_part(const char *fam, double bytes, uint32_t ntiles, const Key<W> *in, const uint32_t *vin, ReadSrc S,
+                     TileMap M, PartLevel L, uint32_t *ghist, uint32_t *cursor, Key<W> *out, uint32_t *vout) {
+        if (ntiles == 0) return;
+        const size_t sm = part_smem(W, PartCfg<W, SRC>::TILE, SRC, HAS_VAL, HIST);
+        auto fn = k_part<W, SRC, HAS_VAL, HIST>;
+        BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sm));
+        KernelTimer t(ctx, fam, bytes);
+        hipLaunchKernelGGL(fn, dim3(ntiles), dim3(PartCfg<W, SRC>::THREADS), sm, ctx->stream, in, vin, S, M, L, ghist, cursor, out,
+                           vout);
+        check_launch(fam);
+    }
+
+    template <int NT, int OP>
+    void launch_bucket(uint32_t nblocks, Key<W> *buf, uint32_t *vals, BucketArgs A, double bytes) {
+        if (nblocks == 0) return;
+        const size_t sm = bucket_smem<W, NT, kBucketItems, OP>();
+        auto fn = k_bucket<W, NT, kBucketItems, OP>;
+        BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sm));
+        KernelTimer t(ctx, "lds_sort", bytes);
+        hipLaunchKernelGGL(fn, dim3(nblocks), dim3(NT), sm, ctx->stream, buf, vals, A);
+        check_launch("k_bucket");
+    }
+
+    template <int OP>
+    void launch_bucket_hash(uint32_t nblocks, Key<W> *buf, uint32_t *vals, BucketArgs A, double bytes) {
+        if constexpr (W == 1) {
+            if (nblocks == 0) return;
+            const size_t sm = bucket_hash_smem<OP>();
+            auto fn = k_bucket_hash<OP>;
+            BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)sm));
+            KernelTimer t(ctx, "lds_dedup", bytes);
+            hipLaunchKernelGGL(fn, dim3(nblocks), dim3(kHashThreads), sm, ctx->stream, buf, vals, A);
+            check_launch("k_bucket_hash");
+        }
+    }
+
+    // unsorted dedup is enough when a later stage sorts the distinct records (HASH mode)
+    bool use_hash_dedup() const { return W == 1 && dmode == MSD_HASH && 2 * k < 64; }
+
+    template <int NT>
+    void bucket_dispatch(uint32_t nblocks, Key<W> *buf, uint32_t *vals, BucketArgs A, double bytes) {
+        if (NT == kBktThreads && use_hash_dedup()) {
+            switch (op) {
+                case MSD_OP_NONE: launch_bucket_hash<0>(nblocks, buf, vals, A, bytes); return;
+                case MSD_OP_COUNT: launch_bucket_hash<1>(nblocks, buf, vals, A, bytes); return;
+                case MSD_OP_SUM: launch_bucket_hash<2>(nblocks, buf, vals, A, bytes); return;
+                case MSD_OP_OR: launch_bucket_hash<3>(nblocks, buf, vals, A, bytes); return;
+                default: BBK_REQUIRE(false, BBK_ERR_ARG, "bad reduce op");
+            }
+        }
+        switch (op) {
+            case MSD_OP_NONE: launch_bucket<NT, 0>(nblocks, buf, vals, A, bytes); break;
+            case MSD_OP_COUNT: launch_bucket<NT, 1>(nblocks, buf, vals, A, bytes); break;
+            case MSD_OP_SUM: launch_bucket<NT, 2>(nblocks, buf, vals, A, bytes); break;
+            case MSD_OP_OR: launch_bucket<NT, 3>(nblocks, buf, vals, A, bytes); break;
+            default: BBK_REQUIRE(false, BBK_ERR_ARG, "bad reduce op");
+        }
+    }
+
+    // returns false if the caller should use the LSD path instead (too much overflow)
+    bool run(const bbk_reads *rd, const void *d_keys, const uint32_t *d_vals, uint64_t n_in, bool with_mask,
+             MsdOutput &out) {
+        constexpr uint32_t kPartTile = PartCfg<W, 0>::TILE;
+        const bool from_reads = rd != nullptr;
+        const bool has_val = with_mask || d_vals != nullptr;
+        const size_t rec = (size_t)W * 8;
+        const int w0bits = (W == 1) ? (int)(2 * k) : 64;
+
+        // ---- instance space
+        DevBuf koff, tile_read;
+        uint64_t N = n_in;
+        if (from_reads) {
+            koff.alloc((rd->n + 1) * sizeof(uint64_t));
+            if (rd->n) {
+                hipLaunchKernelGGL(k_kmers_per_read2, dim3((unsigned)((rd->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   rd->d_len, rd->n, k, koff.as<uint64_t>());
+                check_launch("k_kmers_per_read2");
+            }
+            N = exclusive_scan_u64(ctx, koff.as<uint64_t>(), koff.as<uint64_t>(), rd->n);
+            BBK_HIP(hipMemcpyAsync(koff.as<uint64_t>() + rd->n, &N, sizeof(uint64_t), hipMemcpyHostToDevice,
+                                   ctx->stream));
+        }
+        out.instances = N;
+        out.n = 0;
+        if (N == 0) {
+            out.keys.alloc(16);
+            out.vals.alloc(16);
+            return true;
+        }
+        BBK_REQUIRE(N < (1ull << 32) - kPartTile, BBK_ERR_ARG,
+                    "batch holds %llu records; a single device batch is limited to 2^32-1 (split the input)",
+                    (unsigned long long)N);
+
+        // ---- bin plan: nb1 (power of two) level-1 bins; level-2 bin counts are chosen per segment below
+        const double target = kBucketFill * kBucketCap;
+        const double want = std::max(1.0, std::ceil((double)N / target));
+        uint32_t nb1 = 1;
+        int b1 = 0;
+        while (nb1 < 512 && (double)nb1 * nb1 < want) {
+            nb1 <<= 1;
+            ++b1;
+        }
+        const bool verbose = getenv("BBK_VERBOSE") != nullptr;
+        if (want / nb1 > 0.75 * kMaxBins) {  // would need a third level: leave to the LSD path
+            if (verbose) fprintf(stderr, "[bbk] msd declines: N=%llu needs more than two levels\n", (unsigned long long)N);
+            return false;
+        }
+        PartLevel L1{1, b1, nb1, dmode, w0bits, nullptr, nullptr};
+
+        const uint32_t ntiles1 = (uint32_t)((N + kPartTile - 1) / kPartTile);
+        ReadSrc S{};
+        if (from_reads) {
+            tile_read.alloc(((size_t)ntiles1 + 2) * sizeof(uint32_t));
+            hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1 + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                               koff.as<uint64_t>(), rd->n, (uint64_t)ntiles1, kPartTile, tile_read.as<uint32_t>());
+            check_launch("k_tile_reads");
+            S = ReadSrc{rd->d_words, rd->d_woff, rd->d_len, koff.as<uint64_t>(), tile_read.as<uint32_t>(), rd->n, (int)k};
+        }
+        TileMap M1{nullptr, nullptr, 1, N};
+
+        // ---- level 1: histogram, offsets, scatter
+        DevBuf hist1((size_t)nb1 * 4 + 16), cur1((size_t)nb1 * 4 + 16);
+        BBK_HIP(hipMemsetAsync(hist1.p, 0, (size_t)nb1 * 4 + 16, ctx->stream));
+        const Key<W> *kin = (const Key<W> *)d_keys;
+        if (nb1 > 1) {
+            const double hb = from_reads ? (double)rd->n_words * 8 : (double)N * rec;
+            if (from_reads) {
+                launch_part<1, false, true>("part_hist1", hb, ntiles1, nullptr, nullptr, S, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+            } else {
+                launch_part<0, false, true>("part_hist1", hb, ntiles1, kin, nullptr, S, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+            }
+        } else {
+            const uint32_t n32 = (uint32_t)N;
+            BBK_HIP(hipMemcpyAsync(hist1.p, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        std::vector<uint32_t> h1(nb1), off1(nb1 + 1), tstart(nb1 + 1), snb2(nb1), sbin(nb1 + 1);
+        BBK_HIP(hipMemcpyAsync(h1.data(), hist1.p, (size_t)nb1 * 4, hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        off1[0] = 0;
+        tstart[0] = 0;
+        sbin[0] = 0;
+        for (uint32_t b = 0; b < nb1; ++b) {
+            off1[b + 1] = off1[b] + h1[b];
+            tstart[b + 1] = tstart[b] + (h1[b] + kPartTile - 1) / kPartTile;
+            snb2[b] = (uint32_t)std::min<double>(kMaxBins, std::max(1.0, std::ceil((double)h1[b] / target)));
+            sbin[b + 1] = sbin[b] + snb2[b];
+        }
+        const uint32_t nbuckets = sbin[nb1];
+        BBK_REQUIRE(off1[nb1] == (uint32_t)N, BBK_ERR_INTERNAL, "level-1 histogram does not add up (%u vs %llu)",
+                    off1[nb1], (unsigned long long)N);
+        BBK_HIP(hipMemcpyAsync(cur1.p, off1.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
+
+        DevBuf bufA(N * rec), bufB(N * rec), valA, valB;
+        const bool need_vbuf = has_val || op != MSD_OP_NONE;
+        if (has_val) valA.alloc(N * 4);
+        if (need_vbuf) valB.alloc(N * 4);
+        {
+            const double pb = (from_reads ? (double)rd->n_words * 8 : (double)N * (rec + (has_val ? 4 : 0))) +
+                              (double)N * (rec + (has_val ? 4 : 0));
+            if (from_reads) {
+                if (has_val) launch_part<1, true, false>("part_scatter1", pb, ntiles1, nullptr, nullptr, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
+                else launch_part<1, false, false>("part_scatter1", pb, ntiles1, nullptr, nullptr, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
+            } else {
+                if (has_val) launch_part<0, true, false>("part_scatter1", pb, ntiles1, kin, d_vals, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
+                else launch_part<0, false, false>("part_scatter1", pb, ntiles1, kin, nullptr, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
+            }
+        }
+
+        // ---- level 2
+        DevBuf seg_tile(((size_t)nb1 + 1) * 4), seg_off(((size_t)nb1 + 1) * 4), seg_nb2((size_t)nb1 * 4 + 16),
+            seg_bin(((size_t)nb1 + 1) * 4);
+        BBK_HIP(hipMemcpyAsync(seg_tile.p, tstart.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(seg_off.p, off1.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(seg_nb2.p, snb2.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(seg_bin.p, sbin.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>()};
+        const uint32_t ntiles2 = tstart[nb1];
+        TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), nb1, N};
+        DevBuf hist2((size_t)nbuckets * 4 + 16), boff(((size_t)nbuckets + 1) * 4 + 16);
+        BBK_HIP(hipMemsetAsync(hist2.p, 0, (size_t)nbuckets * 4 + 16, ctx->stream));
+        launch_part<0, false, true>("part_hist2", (double)N * rec, ntiles2, bufA.as<Key<W>>(), nullptr, S, M2, L2,
+                                    hist2.as<uint32_t>(), nullptr, nullptr, nullptr);
+        {
+            DevBuf h64(((size_t)nbuckets + 1) * 8);
+            hipLaunchKernelGGL(k_u32_to_u64, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream,
+                               hist2.as<uint32_t>(), (uint64_t)nbuckets, h64.as<uint64_t>(), 0u);
+            check_launch("k_u32_to_u64");
+            const uint64_t tot = exclusive_scan_u64(ctx, h64.as<uint64_t>(), h64.as<uint64_t>(), nbuckets);
+            BBK_REQUIRE(tot == N, BBK_ERR_INTERNAL, "level-2 histogram does not add up");
+            hipLaunchKernelGGL(k_scan_to_u32, dim3((nbuckets + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                               h64.as<uint64_t>(), (uint64_t)nbuckets, tot, boff.as<uint32_t>());
+            check_launch("k_scan_to_u32");
+            BBK_HIP(hipMemcpyAsync(hist2.p, boff.p, (size_t)nbuckets * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        {
+            const double pb = 2.0 * (double)N * (rec + (has_val ? 4 : 0));
+            if (has_val) launch_part<0, true, false>("part_scatter2", pb, ntiles2, bufA.as<Key<W>>(), valA.as<uint32_t>(), S, M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), valB.as<uint32_t>());
+            else launch_part<0, false, false>("part_scatter2", pb, ntiles2, bufA.as<Key<W>>(), nullptr, S, M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), nullptr);
+        }
+        bufA.release();
+        valA.release();
+
+        // ---- buckets in LDS
+        DevBuf dcount((size_t)nbuckets * 4 + 16);
+        BucketArgs A{boff.as<uint32_t>(), dcount.as<uint32_t>(), nullptr, (int)k};
+        const double bb = (double)N * (rec + (has_val ? 4 : 0));
+        bucket_dispatch<kBktThreads>(nbuckets, bufB.as<Key<W>>(), valB.as<uint32_t>(), A, bb);
+
+        // ---- buckets above CAP: a second pass with 512-thread workgroups (2 x CAP); what still does not
+        // fit (a k-mer repeated > 12 k times in one bucket) is finished by the LSD path, one by one
+        std::vector<uint32_t> hd(nbuckets), hb(nbuckets + 1);
+        BBK_HIP(hipMemcpyAsync(hd.data(), dcount.p, (size_t)nbuckets * 4, hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(hb.data(), boff.p, ((size_t)nbuckets + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        std::vector<uint32_t> big;
+        uint64_t big_rec = 0;
+        // (the 512-thread variant needs 2 x CAP records in LDS: only the 8-byte keys fit in 160 KiB)
+        const bool big_ok = bucket_smem<W, 2 * kBktThreads, kBucketItems, 3>() <= 160 * 1024;
+        for (uint32_t b = 0; b < nbuckets; ++b)
+            if (big_ok && hd[b] == 0xFFFFFFFFu && hb[b + 1] - hb[b] <= kBucketCapBig) {
+                big.push_back(b);
+                big_rec += hb[b + 1] - hb[b];
+            }
+        if constexpr (W == 1) if (!big.empty()) {
+            DevBuf ids(big.size() * 4);
+            BBK_HIP(hipMemcpyAsync(ids.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            BucketArgs A2{boff.as<uint32_t>(), dcount.as<uint32_t>(), ids.as<uint32_t>(), (int)k};
+            bucket_dispatch<2 * kBktThreads>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2,
+                                             (double)big_rec * (rec + (has_val ? 4 : 0)));
+            BBK_HIP(hipMemcpyAsync(hd.data(), dcount.p, (size_t)nbuckets * 4, hipMemcpyDeviceToHost, ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        uint64_t novf = 0, ovf_rec = 0;
+        for (uint32_t b = 0; b < nbuckets; ++b)
+            if (hd[b] == 0xFFFFFFFFu) {
+                ++novf;
+                ovf_rec += hb[b + 1] - hb[b];
+            }
+        if (verbose) {
+            uint32_t mx = 0;
+            for (uint32_t b = 0; b < nbuckets; ++b) mx = std::max(mx, hb[b + 1] - hb[b]);
+            fprintf(stderr, "[bbk] msd mode=%d N=%llu nb1=%u buckets=%u max_bucket=%u cap=%u big=%zu lsd=%llu (%llu rec)\n",
+                    dmode, (unsigned long long)N, nb1, nbuckets, mx, kBucketCap, big.size(), (unsigned long long)novf,
+                    (unsigned long long)ovf_rec);
+        }
+        if (novf > 256 || ovf_rec > N / 4) return false;
+        if (novf) {
+            const ReduceOp rop = op == MSD_OP_OR ? REDUCE_OR : (op == MSD_OP_SUM ? REDUCE_SUM : REDUCE_COUNT);
+            for (uint32_t b = 0; b < nbuckets; ++b) {
+                if (hd[b] != 0xFFFFFFFFu) continue;
+                const uint64_t cnt = hb[b + 1] - hb[b];
+                Key<W> *kb = bufB.as<Key<W>>() + hb[b];
+                uint32_t *vb = need_vbuf ? valB.as<uint32_t>() + hb[b] : nullptr;
+                DevBuf tk(cnt * rec), tv(cnt * 4), ok(cnt * rec), ov(cnt * 4);
+                sort_records(ctx, W, kb, tk.p, has_val ? vb : nullptr, has_val ? tv.as<uint32_t>() : nullptr, cnt,
+                             key_passes(k));
+                const uint64_t d = unique_records(ctx, W, kb, has_val ? vb : nullptr, cnt, ok.p,
+                                                  op != MSD_OP_NONE ? ov.as<uint32_t>() : nullptr, rop, false);
+                BBK_HIP(hipMemcpyAsync(kb, ok.p, d * rec, hipMemcpyDeviceToDevice, ctx->stream));
+                if (op != MSD_OP_NONE)
+                    BBK_HIP(hipMemcpyAsync(vb, ov.p, d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                BBK_HIP(hipStreamSynchronize(ctx->stream));
+                hd[b] = (uint32_t)d;
+            }
+            BBK_HIP(hipMemcpyAsync(dcount.p, hd.data(), (size_t)nbuckets * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        out.overflow_buckets = novf;
+
+        // ---- dense output
+        DevBuf d64(((size_t)nbuckets + 1) * 8);
+        hipLaunchKernelGGL(k_u32_to_u64, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream, dcount.as<uint32_t>(),
+                           (uint64_t)nbuckets, d64.as<uint64_t>(), 0u);
+        check_launch("k_u32_to_u64");
+        const uint64_t D = exclusive_scan_u64(ctx, d64.as<uint64_t>(), d64.as<uint64_t>(), nbuckets);
+        out.n = D;
+        out.keys.alloc(D * rec);
+        const bool out_vals = op != MSD_OP_NONE;
+        if (out_vals) out.vals.alloc(D * 4);
+        {
+            KernelTimer t(ctx, "compact", 2.0 * (double)D * (rec + (out_vals ? 4 : 0)));
+            const unsigned blocks = (unsigned)(((uint64_t)nbuckets * 64 + 255) / 256);
+            if (out_vals)
+                hipLaunchKernelGGL((k_compact<W, true>), dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<Key<W>>(),
+                                   valB.as<uint32_t>(), boff.as<uint32_t>(), dcount.as<uint32_t>(), d64.as<uint64_t>(),
+                                   nbuckets, out.keys.as<Key<W>>(), out.vals.as<uint32_t>());
+            else
+                hipLaunchKernelGGL((k_compact<W, false>), dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<Key<W>>(),
+                                   (const uint32_t *)nullptr, boff.as<uint32_t>(), dcount.as<uint32_t>(),
+                                   d64.as<uint64_t>(), nbuckets, out.keys.as<Key<W>>(), (uint32_t *)nullptr);
+            check_launch("k_compact");
+        }
+        // bucket table for lookups (HASH mode): offsets of every bucket in the dense output
+        out.nbuckets = nbuckets;
+        out.bucket_off.alloc(((size_t)nbuckets + 1) * 4);
+        hipLaunchKernelGGL(k_scan_to_u32, dim3((nbuckets + 1 + 255) / 256), dim3(256), 0, ctx->stream, d64.as<uint64_t>(),
+                           (uint64_t)nbuckets, D, out.bucket_off.as<uint32_t>());
+        check_launch("k_scan_to_u32");
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        return true;
+    }
+};
+
+bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_reads *rd, const void *d_keys,
+                     const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out) {
+    const int W = (int)words_of(k);
+    if (W == 1) {
+        MsdRunner<1> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
+        return r.run(rd, d_keys, d_vals, n, with_mask, out);
+    }
+    if (W == 2) {
+        MsdRunner<2> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
+        return r.run(rd, d_keys, d_vals, n, with_mask, out);
+    }
+    return false;  // wider keys stay on the LSD path for now
+}
+
+}  // namespace bbk
