@@ -187,7 +187,10 @@ __device__ inline void tile_range(const TileMap &M, uint32_t tile, uint32_t kPar
 }
 
 // SRC 0: key array, SRC 1: reads.  HIST_ONLY: accumulate the level histogram; else scatter.
-template <int W, int SRC, bool HAS_VAL, bool HIST_ONLY>
+constexpr int kRelSlots = 1024;  // reads of one tile cached in LDS (150 bp reads: ~64 per tile)
+
+// LVL1: level-1 kernels have at most 512 bins (smaller LDS tables: two workgroups per CU)
+template <int W, int SRC, bool HAS_VAL, bool HIST_ONLY, bool LVL1>
 __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__restrict__ in, const uint32_t *__restrict__ vin,
                                                       ReadSrc S, TileMap M, PartLevel L,
                                                       uint32_t *__restrict__ ghist,    // HIST_ONLY: [nseg * nb]
@@ -195,15 +198,15 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
                                                       Key<W> *__restrict__ out, uint32_t *__restrict__ vout) {
     constexpr int kPartItems = PartCfg<W, SRC>::ITEMS, kPartTile = PartCfg<W, SRC>::TILE,
                   kPartThreads = PartCfg<W, SRC>::THREADS;
-    constexpr int kKoffSlots = kPartTile + 8;  // a tile spans at most TILE + 1 reads (every read has >= 1 record... or 0)
+    constexpr int MAXB = LVL1 ? 512 : kMaxBins;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: lhist[kMaxBins] | lstart[kMaxBins] | goff[kMaxBins] | scan[32] | rel[kKoffSlots] (SRC 1) | stage | vstage
+    // layout: lhist[MAXB] | lstart[MAXB] | goff[MAXB] | scan[32] | rel[kRelSlots] (SRC 1) | stage | vstage
     uint32_t *lhist = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *lstart = lhist + kMaxBins;
-    uint32_t *goff = lstart + kMaxBins;
-    uint32_t *scan_tmp = goff + kMaxBins;
+    uint32_t *lstart = lhist + MAXB;
+    uint32_t *goff = lstart + MAXB;
+    uint32_t *scan_tmp = goff + MAXB;
     uint32_t *s_rel = scan_tmp + 32;
-    unsigned char *after = reinterpret_cast<unsigned char *>(s_rel) + (SRC == 1 ? sizeof(uint32_t) * kKoffSlots : 0);
+    unsigned char *after = reinterpret_cast<unsigned char *>(s_rel) + (SRC == 1 ? sizeof(uint32_t) * kRelSlots : 0);
     Key<W> *stage = reinterpret_cast<Key<W> *>(after);
     uint32_t *vstage = reinterpret_cast<uint32_t *>(after + sizeof(Key<W>) * kPartTile);
 
@@ -216,36 +219,44 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
 
     for (uint32_t b = tid; b < nb; b += kPartThreads) lhist[b] = 0;
     uint32_t r0 = 0, nr = 0;
+    bool cached = true;  // SRC 1: the tile's reads fit the LDS cursor table (else: slow path on global koff)
     uint64_t k0 = 0;  // koff of the tile's first read
     if (SRC == 1) {
         r0 = S.tile_read[blockIdx.x];
         const uint32_t r1 = S.tile_read[blockIdx.x + 1];
         nr = r1 - r0 + 1;  // reads r0..r1 inclusive
-        if (nr > (uint32_t)kKoffSlots - 1) nr = kKoffSlots - 1;  // cannot happen: reads without k-mers own no record
+        cached = nr + 1 <= (uint32_t)kRelSlots;
         k0 = S.koff[r0];
-        for (uint32_t i = tid; i <= nr; i += kPartThreads)
-            s_rel[i] = (r0 + i <= S.n_reads) ? (uint32_t)(S.koff[r0 + i] - k0) : 0xFFFFFFFFu;
+        if (cached)
+            for (uint32_t i = tid; i <= nr; i += kPartThreads)
+                s_rel[i] = (r0 + i <= S.n_reads) ? (uint32_t)(S.koff[r0 + i] - k0) : 0xFFFFFFFFu;
     }
     __syncthreads();
 
     Key<W> keys[kPartItems];
     uint32_t vals[kPartItems];
     uint32_t binrank[kPartItems];  // bin << 16 | rank (rank < 8192 fits 13 bits; bins < 1024)
-    // record owned by (item i, this thread).  Key arrays are read striped over the block (coalesced
-    // 8/16-byte loads); reads are walked wave-contiguously: a wave covers 64 consecutive k-mer
-    // positions per item (they share the read's words in cache) and every lane's record index only
-    // grows, so the read cursor advances linearly.
-    const int lane_ = tid & 63, wave_ = tid >> 6;
+    // Record owned by (item i, this thread).  Key arrays are read striped over the block (coalesced
+    // 8/16-byte loads).  Reads are walked blocked: a lane owns ITEMS consecutive k-mer positions, so
+    // after the first one every k-mer is ROLLED from its predecessor (8-byte keys): with
+    // R = rev2(fwd) kept alongside, one step is fwd = fwd>>2 | b<<2(k-1), R = R<<2 | b<<2(32-k), the
+    // reverse complement is (~R)>>pad and the canonical test is R <= (~fwd)<<pad -- ~15 integer ops
+    // instead of a fresh extraction + bit reversal per position.
     const uint32_t jbase = (uint32_t)(begin - k0);  // SRC 1: tile start relative to its first read
-    uint32_t rl = 0;
-    if (SRC == 1) {
-        const uint32_t first = (uint32_t)(wave_ * (kPartItems * 64));
+    uint32_t rl = 0, nxt = 0;
+    bool have = false;
+    const uint64_t *rw = nullptr;
+    uint32_t Lr = 0, rstart = 0;
+    uint64_t fwd = 0, Rv = 0, wcur = 0;
+    if (SRC == 1 && cached) {
+        const uint32_t first = (uint32_t)tid * kPartItems;
         if (first < count) rl = read_of(s_rel, nr, jbase + first);
+        nxt = s_rel[rl + 1];
+        rstart = s_rel[rl];
     }
 #pragma unroll
     for (int i = 0; i < kPartItems; ++i) {
-        const uint32_t local = (SRC == 1) ? (uint32_t)(wave_ * (kPartItems * 64) + i * 64 + lane_)
-                                          : (uint32_t)(i * kPartThreads + tid);
+        const uint32_t local = (SRC == 1) ? (uint32_t)(tid * kPartItems + i) : (uint32_t)(i * kPartThreads + tid);
         const bool valid = local < count;
 #pragma unroll
         for (int w = 0; w < W; ++w) keys[i].w[w] = 0;
@@ -255,6 +266,77 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
             if (SRC == 0) {
                 keys[i] = key_load<W>(&in[begin + local]);
                 if (HAS_VAL) vals[i] = vin[begin + local];
+            } else if (!cached) {
+                // many tiny reads in one tile: locate every record by a search on the global table
+                const uint64_t j = begin + local;
+                uint64_t lo = r0, hi = (uint64_t)r0 + nr;
+                while (hi - lo > 1) {
+                    const uint64_t mid = (lo + hi) >> 1;
+                    if (S.koff[mid] <= j) lo = mid;
+                    else hi = mid;
+                }
+                const uint32_t p = (uint32_t)(j - S.koff[lo]);
+                const uint64_t *rw2 = S.words + S.woff[lo];
+                const Key<W> f2 = kmer_extract<W>(rw2, p, S.k);
+                const Key<W> c2 = kmer_rc<W>(f2, S.k);
+                const bool min2 = !kmer_less_nucl<W>(c2, f2);
+                keys[i] = key_select<W>(min2, f2, c2);
+                if (HAS_VAL) {
+                    const uint32_t L2 = S.len[lo];
+                    uint32_t m = 0;
+                    if (p + (uint32_t)S.k < L2) {
+                        const uint32_t c = base_at(rw2, p + (uint32_t)S.k);
+                        m |= 1u << (min2 ? c : 7u - c);
+                    }
+                    if (p >= 1) {
+                        const uint32_t c = base_at(rw2, p - 1);
+                        m |= 1u << (min2 ? 4u + c : 3u - c);
+                    }
+                    vals[i] = m;
+                }
+            } else if constexpr (W == 1) {
+                const uint32_t jr = jbase + local;
+                if (jr >= nxt) {  // crossed into a later read
+                    while (rl + 1 < nr && s_rel[rl + 1] <= jr) ++rl;
+                    nxt = s_rel[rl + 1];
+                    rstart = s_rel[rl];
+                    have = false;
+                }
+                const uint32_t p = jr - rstart;
+                const uint32_t k_ = (uint32_t)S.k, pad = 64u - 2u * k_;
+                if (!have) {
+                    const uint64_t r = (uint64_t)r0 + rl;
+                    rw = S.words + S.woff[r];
+                    Lr = S.len[r];
+                    const uint32_t wi = p >> 5, sh = (p & 31u) << 1, lastw = (Lr - 1u) >> 5;
+                    const uint64_t lo = rw[wi];
+                    const uint64_t hi = rw[wi + 1 <= lastw ? wi + 1 : lastw];
+                    fwd = (lo >> sh) | ((hi << 1) << (63u - sh));
+                    fwd = (fwd << pad) >> pad;
+                    Rv = rev2(fwd);
+                    wcur = rw[(p + k_ - 1u) >> 5];
+                    have = true;
+                } else {
+                    const uint32_t q = p + k_ - 1u;  // the base that enters
+                    if ((q & 31u) == 0) wcur = rw[q >> 5];
+                    const uint64_t b = (wcur >> ((q & 31u) << 1)) & 3ull;
+                    fwd = (fwd >> 2) | (b << (2u * (k_ - 1u)));
+                    Rv = (Rv << 2) | (b << pad);
+                }
+                const bool minimal = Rv <= ((~fwd) << pad);
+                keys[i].w[0] = minimal ? fwd : ((~Rv) >> pad);
+                if (HAS_VAL) {
+                    uint32_t m = 0;
+                    if (p + k_ < Lr) {
+                        const uint32_t c = base_at(rw, p + k_);
+                        m |= 1u << (minimal ? c : 7u - c);
+                    }
+                    if (p >= 1) {
+                        const uint32_t c = base_at(rw, p - 1);
+                        m |= 1u << (minimal ? 4u + c : 3u - c);
+                    }
+                    vals[i] = m;
+                }
             } else {
                 read_record<W, HAS_VAL>(S, jbase + local, s_rel, r0, nr, rl, keys[i], vals[i]);
             }
@@ -275,7 +357,7 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
 
     // exclusive scan of the local histogram (<= 1024 bins; BPT bins per thread)
     {
-        constexpr int BPT = kMaxBins / kPartThreads;  // 2 (512 threads) or 1 (1024 threads)
+        constexpr int BPT = (MAXB + kPartThreads - 1) / kPartThreads;
         uint32_t c[BPT];
         uint32_t v = 0;
 #pragma unroll
@@ -331,8 +413,8 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
     }
 }
 
-static size_t part_smem(int W, int tile, int src, bool has_val, bool hist_only) {
-    size_t s = sizeof(uint32_t) * (3 * kMaxBins + 32) + (src == 1 ? sizeof(uint32_t) * ((size_t)tile + 8) : 0);
+static size_t part_smem(int W, int tile, int src, bool has_val, bool hist_only, bool lvl1) {
+    size_t s = sizeof(uint32_t) * (3 * (lvl1 ? 512 : kMaxBins) + 32) + (src == 1 ? sizeof(uint32_t) * kRelSlots : 0);
     if (!hist_only) s += (size_t)W * 8 * tile + (has_val ? 4 * (size_t)tile : 0);
     return s;
 }
@@ -394,11 +476,48 @@ __global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_
     }
     __syncthreads();
 
-    // ---- LSD radix sort over the populated key bits (last word first: word 0 is most significant)
+    // ---- LSD radix sort.  8-byte keys: only the bits in which the bucket's keys differ are sorted
+    // (keys of a KEYS/REF-mode bucket share their top ~16 bits): subtract the bucket minimum, sort
+    // the bits of (max - min).  Wider keys: all populated bits, last word first.
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int lastbits = 2 * A.k - 64 * (W - 1);
+    uint64_t kmin = 0;
+    int sortbits = lastbits;
+    if (W == 1) {
+        uint64_t mn = ~0ull, mx = 0;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t p = (uint32_t)(i * NT + tid);
+            if (p < n) {
+                const uint64_t x = skeys[p].w[0];
+                mn = x < mn ? x : mn;
+                mx = x > mx ? x : mx;
+            }
+        }
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            const uint64_t a = __shfl_xor(mn, dd, 64), c = __shfl_xor(mx, dd, 64);
+            mn = a < mn ? a : mn;
+            mx = c > mx ? c : mx;
+        }
+        uint64_t *mm = reinterpret_cast<uint64_t *>(wave_cnt);  // counters are not live yet
+        if (lane == 0) {
+            mm[2 * wave] = mn;
+            mm[2 * wave + 1] = mx;
+        }
+        __syncthreads();
+        mn = ~0ull;
+        mx = 0;
+        for (int j = 0; j < NWAVES; ++j) {
+            mn = mm[2 * j] < mn ? mm[2 * j] : mn;
+            mx = mm[2 * j + 1] > mx ? mm[2 * j + 1] : mx;
+        }
+        __syncthreads();
+        kmin = mn;
+        sortbits = 64 - __builtin_clzll((mx - mn) | 1ull);
+    }
     for (int w = W - 1; w >= 0; --w) {
-        const int wbits = (w == W - 1) ? lastbits : 64;
+        const int wbits = (W == 1) ? sortbits : ((w == W - 1) ? lastbits : 64);
         for (int shift = 0; shift < wbits; shift += 8) {
             Key<W> keys[ITEMS];
             uint32_t v[ITEMS];
@@ -419,7 +538,8 @@ __global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_
                 if (valid) {
                     keys[i] = key_load<W>(&skeys[p]);
                     if (IN_VAL) v[i] = svals[p];
-                    const uint64_t word = (W == 1) ? keys[i].w[0] : reinterpret_cast<const uint64_t *>(&skeys[p])[w];
+                    const uint64_t word = (W == 1) ? keys[i].w[0] - kmin
+                                                   : reinterpret_cast<const uint64_t *>(&skeys[p])[w];
                     d = (uint32_t)(word >> shift) & 0xFFu;
                 }
                 const uint64_t peers = match8(d, valid);
@@ -714,9 +834,16 @@ struct MsdRunner {
     template <int SRC, bool HAS_VAL, bool HIST>
     void launch_part(const char *fam, double bytes, uint32_t ntiles, const Key<W> *in, const uint32_t *vin, ReadSrc S,
                      TileMap M, PartLevel L, uint32_t *ghist, uint32_t *cursor, Key<W> *out, uint32_t *vout) {
+        if (L.level == 1) launch_part_l<SRC, HAS_VAL, HIST, true>(fam, bytes, ntiles, in, vin, S, M, L, ghist, cursor, out, vout);
+        else launch_part_l<SRC, HAS_VAL, HIST, false>(fam, bytes, ntiles, in, vin, S, M, L, ghist, cursor, out, vout);
+    }
+
+    template <int SRC, bool HAS_VAL, bool HIST, bool LVL1>
+    void launch_part_l(const char *fam, double bytes, uint32_t ntiles, const Key<W> *in, const uint32_t *vin, ReadSrc S,
+                       TileMap M, PartLevel L, uint32_t *ghist, uint32_t *cursor, Key<W> *out, uint32_t *vout) {
         if (ntiles == 0) return;
-        const size_t sm = part_smem(W, PartCfg<W, SRC>::TILE, SRC, HAS_VAL, HIST);
-        auto fn = k_part<W, SRC, HAS_VAL, HIST>;
+        const size_t sm = part_smem(W, PartCfg<W, SRC>::TILE, SRC, HAS_VAL, HIST, LVL1);
+        auto fn = k_part<W, SRC, HAS_VAL, HIST, LVL1>;
         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)sm));
         KernelTimer t(ctx, fam, bytes);

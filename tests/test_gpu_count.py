@@ -156,3 +156,30 @@ def test_owner_matches_host_mirror(ctx):
             own = D.owner_of(part, nranks)
             exp = np.repeat(np.arange(nranks), counts.astype(np.int64))
             assert np.array_equal(own, exp)
+
+
+def test_many_tiny_reads(ctx):
+    """Thousands of reads with one or two k-mers each: a partition tile then spans more reads than
+    its LDS cursor table holds (the slow path of the fused extraction)."""
+    rng = np.random.default_rng(5)
+    k = 21
+    reads = ["".join("ACGT"[i] for i in rng.integers(0, 4, size=k + int(rng.integers(0, 2)))) for _ in range(30000)]
+    reads += ["ACGTAC"] * 50 + ["A" * 400]
+    exp, expc = O.kmercount(reads, k, 16, 2, with_counts=True)
+    got, gotc = gpu_final_kmers(ctx, reads, k, with_counts=True)
+    assert np.array_equal(got, exp) and np.array_equal(gotc, expc)
+    x = ctx.extindex(ctx.reads_from_ascii(reads), k)
+    ox = O.ExtIndex(reads, k, 1)
+    order = np.lexsort([ox.kmers[:, 0]])
+    gk, gm = x.export()
+    assert np.array_equal(gk, ox.kmers[order]) and np.array_equal(gm, ox.masks[order])
+
+
+def test_high_multiplicity_overflow(ctx):
+    """One k-mer repeated far more often than a bucket holds (poly-A reads) next to normal reads:
+    exercises the oversize-bucket paths of the MSD sort."""
+    reads = synth_reads(3000, read_len=150, genome_len=20000, seed=12) + ["A" * 150] * 400 + ["ACGT" * 37] * 300
+    for k in (21, 33):
+        exp, expc = O.kmercount(reads, k, 16, 2, with_counts=True)
+        got, gotc = gpu_final_kmers(ctx, reads, k, with_counts=True)
+        assert np.array_equal(got, exp) and np.array_equal(gotc, expc)
