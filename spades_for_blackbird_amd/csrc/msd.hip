@@ -969,9 +969,9 @@ struct MsdRunner {
         if (nb1 > 1) {
             const double hb = from_reads ? (double)rd->n_words * 8 : (double)N * rec;
             if (from_reads) {
-                launch_part<1, false, true>("part_hist1", hb, ntiles1, nullptr, nullptr, S, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+                launch_part<1, false, true>("part_hist1_reads", hb, ntiles1, nullptr, nullptr, S, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
             } else {
-                launch_part<0, false, true>("part_hist1", hb, ntiles1, kin, nullptr, S, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+                launch_part<0, false, true>("part_hist1_keys", hb, ntiles1, kin, nullptr, S, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
             }
         } else {
             const uint32_t n32 = (uint32_t)N;
@@ -1002,11 +1002,11 @@ struct MsdRunner {
             const double pb = (from_reads ? (double)rd->n_words * 8 : (double)N * (rec + (has_val ? 4 : 0))) +
                               (double)N * (rec + (has_val ? 4 : 0));
             if (from_reads) {
-                if (has_val) launch_part<1, true, false>("part_scatter1", pb, ntiles1, nullptr, nullptr, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
-                else launch_part<1, false, false>("part_scatter1", pb, ntiles1, nullptr, nullptr, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
+                if (has_val) launch_part<1, true, false>("part_scatter1_reads", pb, ntiles1, nullptr, nullptr, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
+                else launch_part<1, false, false>("part_scatter1_reads", pb, ntiles1, nullptr, nullptr, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
             } else {
-                if (has_val) launch_part<0, true, false>("part_scatter1", pb, ntiles1, kin, d_vals, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
-                else launch_part<0, false, false>("part_scatter1", pb, ntiles1, kin, nullptr, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
+                if (has_val) launch_part<0, true, false>("part_scatter1_keys", pb, ntiles1, kin, d_vals, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
+                else launch_part<0, false, false>("part_scatter1_keys", pb, ntiles1, kin, nullptr, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
             }
         }
 
