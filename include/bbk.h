@@ -129,6 +129,12 @@ void bbk_extindex_free(bbk_extindex *x);
  *      and FastGraphFromSequencesConstructor::ConstructGraph
  *      (common/assembly_graph/construction/debruijn_graph_constructor.hpp:182-388,390-518) ----- */
 int bbk_unitigs_build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs **out);
+/* `-c`: coverage of every condensed edge = sum over its (k+1)-mers of their multiplicity in
+ * reads + rc(reads) (CoverageHashMapBuilder, common/utils/ph_map/coverage_hash_map_builder.hpp:15-54;
+ * FillCoverageAndFlankingFromPHM, assembly_graph/graph_support/coverage_filling.hpp:44-62).  After this
+ * call the GFA carries DP:f:<KC/(len-k)> and KC:i:<KC> (projects/gbuilder/main.cpp:200-211). */
+int bbk_unitigs_add_coverage(bbk_ctx *ctx, bbk_unitigs *u, const bbk_reads *reads);
+int bbk_unitigs_export_kc(bbk_ctx *ctx, const bbk_unitigs *u, uint64_t *h_kc);
 uint64_t bbk_unitigs_count(const bbk_unitigs *u);
 uint64_t bbk_unitigs_loops(const bbk_unitigs *u);
 uint64_t bbk_unitigs_total_bases(const bbk_unitigs *u);

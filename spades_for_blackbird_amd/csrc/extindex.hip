@@ -41,23 +41,28 @@ __global__ void k_prefix_table(const uint64_t *__restrict__ keys, int W, uint64_
         for (uint32_t u = t + 1; u <= nbins; ++u) pref[u] = (uint32_t)n;
 }
 
-void build_prefix_table(bbk_ctx *ctx, bbk_extindex *x) {
-    // ~8 keys per bin; word 0 holds min(2k, 64) populated bits
-    const int w0bits = (x->W == 1) ? (int)(2 * x->k) : 64;
+// Prefix table over an ascending key array: ~8 keys per bin; word 0 holds min(2k, 64) populated bits.
+// Returns the number of prefix bits; lookups shift word 0 right by (w0bits - bits).
+unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsigned k, uint64_t n, DevBuf &prefix) {
+    const int w0bits = (W == 1) ? (int)(2 * k) : 64;
     int bits = 4;
-    while (bits < 24 && (1ull << (bits + 3)) < x->n) ++bits;
+    while (bits < 24 && (1ull << (bits + 3)) < n) ++bits;
     bits = std::min(bits, w0bits);
-    x->prefix_bits = (unsigned)bits;
     const uint32_t nbins = 1u << bits;
-    x->prefix.alloc(((size_t)nbins + 1) * sizeof(uint32_t));
-    if (x->n == 0) {
-        BBK_HIP(hipMemsetAsync(x->prefix.p, 0, ((size_t)nbins + 1) * sizeof(uint32_t), ctx->stream));
+    prefix.alloc(((size_t)nbins + 1) * sizeof(uint32_t));
+    if (n == 0) {
+        BBK_HIP(hipMemsetAsync(prefix.p, 0, ((size_t)nbins + 1) * sizeof(uint32_t), ctx->stream));
     } else {
-        hipLaunchKernelGGL(k_prefix_table, dim3((unsigned)((x->n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           x->keys.as<uint64_t>(), (int)x->W, x->n, w0bits - bits, nbins, x->prefix.as<uint32_t>());
+        hipLaunchKernelGGL(k_prefix_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, keys, (int)W, n,
+                           w0bits - bits, nbins, prefix.as<uint32_t>());
         check_launch("k_prefix_table");
     }
     BBK_HIP(hipStreamSynchronize(ctx->stream));
+    return (unsigned)bits;
+}
+
+void build_prefix_table(bbk_ctx *ctx, bbk_extindex *x) {
+    x->prefix_bits = build_prefix_index(ctx, x->keys.as<uint64_t>(), x->W, x->k, x->n, x->prefix);
 }
 
 }  // namespace bbk

@@ -30,6 +30,8 @@ struct bbk_unitigs {
     std::vector<char> bases;        // concatenated ACGT
     std::vector<uint64_t> offsets;  // n + 1
     std::vector<uint32_t> links;    // 4 per link: from, from_plus, to, to_plus
+    bool has_cov = false;
+    std::vector<uint64_t> kc;       // per unitig: sum of (k+1)-mer multiplicities (KC:i:)
 };
 
 namespace bbk {
@@ -517,11 +519,97 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     U.n_links = U.links.size() / 4;
 }
 
+unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsigned k, uint64_t n, DevBuf &prefix);
+
+// One thread per unitig: roll the (k+1)-mers of the sequence, look the canonical form up in the
+// sorted (k+1)-mer count table, add the multiplicities (GraphCoverageFiller,
+// assembly_graph/graph_support/coverage_filling.hpp:44-62).
+template <int W>
+__global__ __launch_bounds__(256) void k_unitig_kc(const char *__restrict__ bases, const uint64_t *__restrict__ off,
+                                                  uint64_t n_unitigs, int k1, const Key<W> *__restrict__ keys,
+                                                  const uint32_t *__restrict__ counts, const uint32_t *__restrict__ pref,
+                                                  int pshift, uint64_t *__restrict__ kc, uint32_t *__restrict__ err) {
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_unitigs) return;
+    const char *s = bases + off[u];
+    const uint64_t len = off[u + 1] - off[u];
+    uint64_t sum = 0;
+    if (len >= (uint64_t)k1) {
+        Key<W> cur;
+#pragma unroll
+        for (int j = 0; j < W; ++j) cur.w[j] = 0;
+        auto code = [](char c) -> uint32_t { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : 3u; };
+        for (int i = 0; i < k1 - 1; ++i) cur = kmer_shl<W>(cur, k1, code(s[i]));
+        for (uint64_t p = (uint64_t)k1 - 1; p < len; ++p) {
+            cur = kmer_shl<W>(cur, k1, code(s[p]));
+            const Key<W> rc = kmer_rc<W>(cur, k1);
+            const bool minimal = !kmer_less_nucl<W>(rc, cur);
+            const Key<W> q = key_select<W>(minimal, cur, rc);
+            const uint32_t j = find_kmer<W>(keys, pref, pshift, q);
+            if (j == 0xFFFFFFFFu) atomicOr(err, 4u);
+            else sum += counts[j];
+        }
+    }
+    kc[u] = sum;
+}
+
+template <int W>
+static void run_kc(bbk_ctx *ctx, const char *d_bases, const uint64_t *d_off, uint64_t nu, unsigned k1,
+                   const bbk_kmerset *set, const DevBuf &pref, unsigned pbits, uint64_t *d_kc, uint32_t *d_err) {
+    const int w0bits = (W == 1) ? (int)(2 * k1) : 64;
+    KernelTimer t(ctx, "coverage", 0);
+    hipLaunchKernelGGL(k_unitig_kc<W>, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, d_off, nu,
+                       (int)k1, set->keys.as<Key<W>>(), set->counts.as<uint32_t>(), pref.as<uint32_t>(),
+                       w0bits - (int)pbits, d_kc, d_err);
+    check_launch("k_unitig_kc");
+}
+
 }  // namespace bbk
 
 using namespace bbk;
 
 extern "C" {
+
+int bbk_unitigs_add_coverage(bbk_ctx *ctx, bbk_unitigs *u, const bbk_reads *reads) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && u && reads, BBK_ERR_ARG, "bbk_unitigs_add_coverage: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        const unsigned k1 = u->k + 1;
+        // multiplicities of the canonical (k+1)-mers over reads + rc(reads)
+        // (CoverageHashMapBuilder::FillCoverageFromStream, utils/ph_map/coverage_hash_map_builder.hpp:15-38)
+        bbk_kmerset *set = nullptr;
+        const int rc = bbk_count(ctx, reads, k1, BBK_CANONICAL | BBK_WITH_COUNTS, &set);
+        if (rc != BBK_OK) throw Error{rc};
+        std::unique_ptr<bbk_kmerset, void (*)(bbk_kmerset *)> guard(set, bbk_kmerset_free);
+        u->kc.assign(u->n, 0);
+        u->has_cov = true;
+        if (u->n == 0) return;
+        DevBuf pref;
+        const unsigned pbits = build_prefix_index(ctx, set->keys.as<uint64_t>(), set->W, k1, set->n, pref);
+        DevBuf d_bases(u->bases.size() + 16), d_off((u->n + 1) * 8), d_kc(u->n * 8), d_err(16);
+        BBK_HIP(hipMemcpyAsync(d_bases.p, u->bases.data(), u->bases.size(), hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(d_off.p, u->offsets.data(), (u->n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipMemsetAsync(d_err.p, 0, 16, ctx->stream));
+        switch (set->W) {
+            case 1: run_kc<1>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
+            case 2: run_kc<2>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
+            case 3: run_kc<3>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
+            case 4: run_kc<4>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
+            default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %u", set->W);
+        }
+        uint32_t herr = 0;
+        d2h(ctx, &herr, d_err.p, 4);
+        BBK_REQUIRE(herr == 0, BBK_ERR_INTERNAL, "coverage: a (k+1)-mer of a unitig is missing from the count table");
+        d2h(ctx, u->kc.data(), d_kc.p, u->n * 8);
+    });
+}
+
+int bbk_unitigs_export_kc(bbk_ctx *ctx, const bbk_unitigs *u, uint64_t *h_kc) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && u && h_kc && u->has_cov, BBK_ERR_ARG, "bbk_unitigs_export_kc: no coverage (call bbk_unitigs_add_coverage)");
+        if (u->n) memcpy(h_kc, u->kc.data(), u->n * sizeof(uint64_t));
+    });
+}
 
 int bbk_unitigs_build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs **out) {
     return guarded([&] {
@@ -572,12 +660,26 @@ int bbk_unitigs_write_gfa(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) 
         // min_id + 2i, debruijn_graph_constructor.hpp:457-458); coverage is 0 without -c.
         const uint64_t n = u->n;
         std::vector<uint64_t> pos(n + 1, 0);
-        static const char tail[] = "\tDP:f:0\tKC:i:0\n";
-        const size_t tail_len = sizeof(tail) - 1;
+        // per-segment tail "\tDP:f:<float(KC/(len-k))>\tKC:i:<KC>\n": default ostream formatting of a float
+        // is %g with 6 significant digits (gfa_writer.cpp:18-25; coverage = raw / length, coverage.hpp:58-64)
+        std::vector<std::string> tails;
+        static const char tail0[] = "\tDP:f:0\tKC:i:0\n";
+        if (u->has_cov) {
+            tails.resize(n);
+#pragma omp parallel for schedule(static)
+            for (uint64_t i = 0; i < n; ++i) {
+                const uint64_t len = u->offsets[i + 1] - u->offsets[i];
+                const double cov = (double)u->kc[i] / (double)(len - u->k);
+                char b[96];
+                snprintf(b, sizeof(b), "\tDP:f:%g\tKC:i:%llu\n", (double)(float)cov, (unsigned long long)u->kc[i]);
+                tails[i] = b;
+            }
+        }
         for (uint64_t i = 0; i < n; ++i) {
             char tmp[24];
             const size_t idl = fmt_u64(tmp, 3 + 2 * i);
-            pos[i + 1] = pos[i] + 2 + idl + 1 + (u->offsets[i + 1] - u->offsets[i]) + tail_len;
+            const size_t tl = u->has_cov ? tails[i].size() : sizeof(tail0) - 1;
+            pos[i + 1] = pos[i] + 2 + idl + 1 + (u->offsets[i + 1] - u->offsets[i]) + tl;
         }
         std::vector<char> buf(pos[n]);
 #pragma omp parallel for schedule(static)
@@ -590,7 +692,8 @@ int bbk_unitigs_write_gfa(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) 
             const uint64_t len = u->offsets[i + 1] - u->offsets[i];
             memcpy(d, u->bases.data() + u->offsets[i], len);
             d += len;
-            memcpy(d, tail, tail_len);
+            if (u->has_cov) memcpy(d, tails[i].data(), tails[i].size());
+            else memcpy(d, tail0, sizeof(tail0) - 1);
         }
         FILE *f = fopen(path, "wb");
         BBK_REQUIRE(f != nullptr, BBK_ERR_IO, "cannot open %s for writing", path);

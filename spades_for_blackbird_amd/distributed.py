@@ -44,6 +44,10 @@ def exchange_by_owner(send, send_counts, words, group=None):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     dev = send.device
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+        # gloo has no device all_to_all: stage through the host (tests of the sharded path on one GPU)
+        recv, rcl = exchange_by_owner(send.cpu(), send_counts, words, group)
+        return recv.to(dev), rcl
     sc = torch.tensor([int(x) for x in send_counts], dtype=torch.int64, device=dev)
     rc = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(rc, sc, group=group)

@@ -20,7 +20,7 @@ SYMBOLS = [
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_free",
-    "bbk_unitigs_build", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
+    "bbk_unitigs_build", "bbk_unitigs_add_coverage", "bbk_unitigs_export_kc", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
     "bbk_unitigs_vertices", "bbk_unitigs_links", "bbk_unitigs_export", "bbk_unitigs_export_links",
     "bbk_unitigs_write_gfa", "bbk_unitigs_write_fasta", "bbk_unitigs_free",
 ]
@@ -92,6 +92,8 @@ def load_library():
         for f in ("count", "loops", "total_bases", "vertices", "links"):
             getattr(L, "bbk_unitigs_" + f).restype = u64
             getattr(L, "bbk_unitigs_" + f).argtypes = [vp]
+        L.bbk_unitigs_add_coverage.argtypes = [vp, vp, vp]
+        L.bbk_unitigs_export_kc.argtypes = [vp, vp, vp]
         L.bbk_unitigs_export.argtypes = [vp, vp, vp, vp]
         L.bbk_unitigs_export_links.argtypes = [vp, vp, vp]
         L.bbk_unitigs_write_gfa.argtypes = [vp, vp, C.c_char_p]
@@ -354,6 +356,15 @@ class Unitigs(_Handle):
         _check(self._L.bbk_unitigs_export(self.ctx._h, self._h, _ptr(buf), _ptr(offs)))
         b = buf.tobytes()
         return [b[int(offs[i]):int(offs[i + 1])].decode() for i in range(n)]
+
+    def add_coverage(self, reads):
+        """gbuilder -c: KC / DP of every condensed edge from the reads."""
+        _check(self._L.bbk_unitigs_add_coverage(self.ctx._h, self._h, reads._h))
+
+    def kc(self):
+        a = np.zeros(len(self), dtype=np.uint64)
+        _check(self._L.bbk_unitigs_export_kc(self.ctx._h, self._h, _ptr(a)))
+        return a
 
     def links(self):
         a = np.zeros((self.n_links, 4), dtype=np.uint32)

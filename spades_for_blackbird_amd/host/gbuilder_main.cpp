@@ -4,7 +4,7 @@
 // and the same flow (:103-237): reads -> extension index -> unbranching paths + loops ->
 // unitig FASTA or graph -> GFA, with every step behind the C ABI (include/bbk.h).
 // -t/-tmp-dir/-b are accepted for compatibility (no temp files, no per-thread buffers here).
-// --fastg, --spades and -c are SURVEY 8(f) "next" rows and are refused with a clear message.
+// --fastg and --spades are SURVEY 8(f) "next" rows and are refused with a clear message.
 #include <cstring>
 #include <string>
 #include <vector>
@@ -73,7 +73,7 @@ int main(int argc, char **argv) {
     }
     if (mode == FASTG || mode == SPADES)
         fatal("this build writes --unitigs and --gfa; FASTG / SPAdes-binary output is not implemented yet");
-    if (coverage) fatal("this build does not infer coverage (-c) yet");
+    if (coverage && mode == UNITIGS) info("Note: -c has no effect on --unitigs output");
 
     // LoadDataset (:89-101)
     std::vector<std::string> files;
@@ -112,6 +112,11 @@ int main(int argc, char **argv) {
     } else {
         info("Total %llu edges to create", (unsigned long long)(2 * bbk_unitigs_count(u)));
         info("Total %llu vertices to create", (unsigned long long)bbk_unitigs_vertices(u));
+        if (coverage) {  // Step 4: infer coverage (projects/gbuilder/main.cpp:200-211)
+            info("Filling coverage index");
+            check(bbk_unitigs_add_coverage(ctx, u, reads), "bbk_unitigs_add_coverage");
+            info("Filling coverage and flanking coverage from PHM");
+        }
         info("Saving graph to %s", outfile.c_str());
         check(bbk_unitigs_write_gfa(ctx, u, outfile.c_str()), "bbk_unitigs_write_gfa");
     }

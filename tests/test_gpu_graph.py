@@ -170,3 +170,45 @@ def test_even_k_rejected(ctx):
     x = ctx.extindex(r, 4)
     with pytest.raises(B.BBKError):
         ctx.unitigs(x)
+
+
+def test_coverage_toy_golden(ctx, golden, golden_dir, tmp_path):
+    """gbuilder -c on the bundled toy data: KC and DP of the reference run."""
+    g = golden["toy_gbuilder"]
+    reads = read_fastq_gz(os.path.join(golden_dir, g["file"]))
+    r = ctx.reads_from_ascii(reads)
+    u = ctx.unitigs(ctx.extindex(r, 21))
+    u.add_coverage(r)
+    assert sorted(int(x) for x in u.kc()) == sorted(g["k21"]["KC"])
+    p = str(tmp_path / "c.gfa")
+    u.write_gfa(p)
+    txt = open(p).read()
+    dp = sorted(l.split("\t")[3][5:] for l in txt.splitlines() if l.startswith("S"))
+    assert dp == sorted(g["k21"]["DP"])
+    exp = O.ExtIndex(reads, 21, 1).unitigs().gfa(with_cov=True)[0]
+    assert gfa_canon.canon_md5(txt, with_kc=True) == gfa_canon.canon_md5(exp, with_kc=True)
+    by_seq = {l.split("\t")[2]: l.split("\t", 3)[3] for l in txt.splitlines() if l.startswith("S")}
+    exp_by_seq = {l.split("\t")[2]: l.split("\t", 3)[3] for l in exp.splitlines() if l.startswith("S")}
+    assert by_seq == exp_by_seq  # identical DP:f / KC:i text per segment
+
+
+def test_coverage_kat_and_synthetic(ctx, golden, tmp_path):
+    g = golden["construction_coverage_k3"]
+    r = ctx.reads_from_ascii(g["reads"])
+    u = ctx.unitigs(ctx.extindex(r, g["k"]))
+    u.add_coverage(r)
+    got = {}
+    for s, kc in zip(u.sequences(), u.kc()):
+        got[s] = int(kc)
+        got[rc(s)] = int(kc)
+    for e, cov in g["coverage"].items():
+        assert got[e] == cov
+    for k, seed in ((21, 31), (33, 32), (55, 33)):
+        reads = synth_reads(800, read_len=100, genome_len=3000, sub_rate=0.01, seed=seed, n_rate=0.001)
+        r = ctx.reads_from_ascii(reads)
+        u = ctx.unitigs(ctx.extindex(r, k))
+        u.add_coverage(r)
+        p = str(tmp_path / ("c%d.gfa" % k))
+        u.write_gfa(p)
+        exp = O.ExtIndex(reads, k, 2).unitigs().gfa(with_cov=True)[0]
+        assert gfa_canon.canon_md5(open(p).read(), with_kc=True) == gfa_canon.canon_md5(exp, with_kc=True)
