@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -106,6 +107,23 @@ struct DevBuf {
     }
 };
 
+// std::vector whose resize() does not zero-fill (multi-hundred-MB host buffers that are about to
+// be overwritten by a device-to-host copy)
+template <class T>
+struct default_init_alloc : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = default_init_alloc<U>;
+    };
+    template <class U, class... A>
+    void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+        else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T>
+using raw_vector = std::vector<T, default_init_alloc<T>>;
+
 struct FamilyStat {
     double ms = 0;
     uint64_t launches = 0;
@@ -129,6 +147,9 @@ struct bbk_ctx {
     std::vector<Pending> pending;
     std::map<std::string, bbk::FamilyStat> stats;
     void resolve_pending();
+    // pinned staging for large device-to-host copies (pageable copies run at a fraction of PCIe)
+    void *pinned[2] = {nullptr, nullptr};
+    size_t pinned_bytes = 0;
 };
 
 namespace bbk {
@@ -163,6 +184,10 @@ inline void check_launch(const char *what) {
 }
 
 inline unsigned words_of(unsigned k) { return (k + 31) >> 5; }
+
+// Large device -> host copy through the context's pinned staging buffers (chunked, two buffers:
+// the copy of chunk i+1 overlaps the host memcpy of chunk i).
+void d2h_big(bbk_ctx *ctx, void *dst, const void *src, size_t bytes);
 
 // ---- primitives.hip -------------------------------------------------------------------------
 // One LSD pass selector: kind 0 = bits [shift, shift+bits) of key word `word`;

@@ -9,6 +9,7 @@
 // (kmer_index_builder.hpp:281-365).  Integer/HBM-bound work: no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstring>
 #include <map>
@@ -83,6 +84,38 @@ void pool_trim() {
     for (auto &kv : pool().free_blocks) (void)hipFree(kv.second);
     pool().free_blocks.clear();
     pool().cached_bytes = 0;
+}
+
+void d2h_big(bbk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    constexpr size_t kChunk = 32ull << 20;
+    if (bytes < (4ull << 20)) {
+        BBK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        return;
+    }
+    if (!ctx->pinned[0]) {
+        BBK_HIP(hipHostMalloc(&ctx->pinned[0], kChunk, hipHostMallocDefault));
+        BBK_HIP(hipHostMalloc(&ctx->pinned[1], kChunk, hipHostMallocDefault));
+        ctx->pinned_bytes = kChunk;
+    }
+    hipEvent_t ev[2];
+    BBK_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    BBK_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+    auto issue = [&](size_t c) {
+        const size_t off = c * kChunk, sz = std::min(kChunk, bytes - off);
+        (void)hipMemcpyAsync(ctx->pinned[c & 1], (const char *)src + off, sz, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipEventRecord(ev[c & 1], ctx->stream);
+    };
+    issue(0);
+    for (size_t c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) issue(c + 1);
+        BBK_HIP(hipEventSynchronize(ev[c & 1]));
+        const size_t off = c * kChunk, sz = std::min(kChunk, bytes - off);
+        memcpy((char *)dst + off, ctx->pinned[c & 1], sz);
+    }
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
 }
 
 constexpr int kThreads = 256;
@@ -793,6 +826,8 @@ int bbk_ctx_destroy(bbk_ctx *ctx) {
     ctx->resolve_pending();
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     bbk::pool_trim();
+    if (ctx->pinned[0]) (void)hipHostFree(ctx->pinned[0]);
+    if (ctx->pinned[1]) (void)hipHostFree(ctx->pinned[1]);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return BBK_OK;

@@ -140,7 +140,7 @@ int bbk_reads_from_ascii(bbk_ctx *ctx, const char *h_bases, const uint64_t *h_of
         }
         woff[n_reads] = nw;
         std::vector<uint64_t> words(nw + 1, 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(32)
         for (uint64_t r = 0; r < n_reads; ++r) {
             const char *s = h_bases + from[r];
             uint64_t *w = words.data() + woff[r];

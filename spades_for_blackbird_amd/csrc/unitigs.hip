@@ -14,6 +14,10 @@
 //   io/graph/gfa_writer.cpp:18-52 and projects/gbuilder/main.cpp:183-192 for the text formats.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <omp.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -27,9 +31,9 @@
 struct bbk_unitigs {
     unsigned k = 0;
     uint64_t n = 0, n_loops = 0, n_vertices = 0, n_links = 0;
-    std::vector<char> bases;        // concatenated ACGT
-    std::vector<uint64_t> offsets;  // n + 1
-    std::vector<uint32_t> links;    // 4 per link: from, from_plus, to, to_plus
+    bbk::raw_vector<char> bases;        // concatenated ACGT
+    bbk::raw_vector<uint64_t> offsets;  // n + 1
+    bbk::raw_vector<uint32_t> links;    // 2 per link: (from << 1 | from_plus), (to << 1 | to_plus)
     bool has_cov = false;
     std::vector<uint64_t> kc;       // per unitig: sum of (k+1)-mer multiplicities (KC:i:)
 };
@@ -90,6 +94,7 @@ struct WalkOut {
     char *bases;
     uint64_t *uoff;        // [U] base offset of unitig
     uint64_t *rec;         // [2U] link records: (idx<<2 | is_rc<<1 | is_start), ~0 = none
+    uint8_t *selfconj;     // [U] the unitig equals its own reverse complement
     uint8_t *visited;      // [n]
     uint32_t *err;
 };
@@ -166,6 +171,7 @@ __global__ __launch_bounds__(256) void k_walk(const Key<W> *__restrict__ keys, c
         // StartLink / EndLink (:432-448): canonical form of the end k-mers, is_rc = k-mer is not it
         o.rec[2 * u] = ((uint64_t)i << 2) | ((uint64_t)(s_rc ? 1 : 0) << 1) | 1ull;
         o.rec[2 * u + 1] = selfconj ? ~0ull : (((uint64_t)j << 2) | ((uint64_t)(cur_min ? 0 : 1) << 1));
+        o.selfconj[u] = selfconj ? 1 : 0;
     }
 }
 
@@ -181,6 +187,62 @@ __global__ void k_compact_candidates(const uint64_t *__restrict__ flag_scan, con
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (!mask_is_junction(masks[i]) && !visited[i]) idx[flag_scan[i]] = (uint32_t)i;
+}
+
+// Links from the sorted link records (vertices = groups of equal canonical k-mer index): for every
+// canonical vertex every (incoming, outgoing) pair (GFAWriter::WriteLinks, io/graph/gfa_writer.cpp:43-52,
+// over the edge lists ConstructionHelper::LinkIncomingEdge/LinkOutgoingEdge build,
+// assembly_graph/core/construction_helper.hpp:80-90).  The group head does the work of its group.
+__device__ inline bool rec_incoming(uint64_t key) {
+    const bool st = key & 1, rc = (key >> 1) & 1;
+    return (!st && !rc) || (st && rc);
+}
+__device__ inline bool rec_outgoing(uint64_t key) {
+    const bool st = key & 1, rc = (key >> 1) & 1;
+    return (st && !rc) || (!st && rc);
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_links(const uint64_t *__restrict__ key, const uint32_t *__restrict__ edge,
+                                              uint64_t nrec, const uint8_t *__restrict__ selfconj,
+                                              uint64_t *__restrict__ cnt, const uint64_t *__restrict__ off,
+                                              uint32_t *__restrict__ links, unsigned long long *__restrict__ nvert) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    const uint64_t kr = key[r];
+    const bool head = kr != ~0ull && (r == 0 || (key[r - 1] >> 2) != (kr >> 2));
+    if (!head) {
+        if (!WRITE) cnt[r] = 0;
+        return;
+    }
+    uint64_t e = r;
+    uint32_t nin = 0, nout = 0;
+    while (e < nrec && key[e] != ~0ull && (key[e] >> 2) == (kr >> 2)) {
+        nin += rec_incoming(key[e]) ? 1u : 0u;
+        nout += rec_outgoing(key[e]) ? 1u : 0u;
+        ++e;
+    }
+    if (!WRITE) {
+        cnt[r] = (uint64_t)nin * nout;
+        atomicAdd(nvert, 1ull);
+        return;
+    }
+    uint64_t o = off[r];
+    for (uint64_t a = r; a < e; ++a) {
+        const uint64_t ka = key[a];
+        if (!rec_incoming(ka)) continue;
+        const uint32_t ea = edge[a];
+        const uint32_t oa = (!(ka & 1) || selfconj[ea]) ? 1u : 0u;
+        for (uint64_t b = r; b < e; ++b) {
+            const uint64_t kb = key[b];
+            if (!rec_outgoing(kb)) continue;
+            const uint32_t eb = edge[b];
+            const uint32_t ob = ((kb & 1) || selfconj[eb]) ? 1u : 0u;
+            links[2 * o] = (ea << 1) | oa;
+            links[2 * o + 1] = (eb << 1) | ob;
+            ++o;
+        }
+    }
 }
 
 __global__ void k_edge_ids(uint32_t *__restrict__ ids, uint64_t n2) {
@@ -316,7 +378,8 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     BBK_REQUIRE(NU < (1ull << 31), BBK_ERR_ARG, "too many unitigs for one device batch");
 
     // ---- pass 1: bases + link records
-    DevBuf bases(NB + 16), uoff((NU + 1) * 8), rec((2 * NU + 2) * 8);
+    DevBuf bases(NB + 16), uoff((NU + 1) * 8), rec((2 * NU + 2) * 8), selfc(NU + 16);
+    o.selfconj = selfc.as<uint8_t>();
     o.uid = uid.as<uint64_t>();
     o.boff = boff.as<uint64_t>();
     o.bases = bases.as<char>();
@@ -328,9 +391,8 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
 
     U.bases.resize(NB);
     U.offsets.resize(NU + 1);
-    if (NB) BBK_HIP(hipMemcpyAsync(U.bases.data(), bases.p, NB, hipMemcpyDeviceToHost, ctx->stream));
-    if (NU) BBK_HIP(hipMemcpyAsync(U.offsets.data(), uoff.p, NU * 8, hipMemcpyDeviceToHost, ctx->stream));
-    BBK_HIP(hipStreamSynchronize(ctx->stream));
+    if (NB) d2h_big(ctx, U.bases.data(), bases.p, NB);
+    if (NU) d2h_big(ctx, U.offsets.data(), uoff.p, NU * 8);
     U.offsets[NU] = NB;
     starts.release();
     keep.release();
@@ -338,6 +400,13 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     uid.release();
     boff.release();
     bases.release();
+
+    // ---- loop candidates first: without perfect loops (the common case) links are made on the device
+    DevBuf flag((n + 1) * 8);
+    hipLaunchKernelGGL(k_loop_candidates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       x->masks.as<uint8_t>(), visited.as<uint8_t>(), n, flag.as<uint64_t>());
+    check_launch("k_loop_candidates");
+    const uint64_t NC = exclusive_scan_u64(ctx, flag.as<uint64_t>(), flag.as<uint64_t>(), n);
 
     // ---- link records: sort by (key, edge) on the device
     std::vector<LinkRec> recs;
@@ -349,17 +418,39 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
         int bits = 2;
         while ((1ull << (bits - 2)) < n + 1) ++bits;
         std::vector<PassDesc> passes;
-        for (int s = 0; s < 64; s += 8) {
-            // keys are either < 2^bits or ~0 (no record): sorting all 64 bits keeps ~0 last; passes above
-            // `bits` see only digit 0x00 or 0xFF and are cheap but needed for ~0 to sort last
-            passes.push_back({0, 0, s, 8, 0});
-        }
+        // keys are either < 2^bits or ~0 (no record): the low `bits` bits order the real records; one
+        // final pass on the top byte (0x00 vs 0xFF) moves the "no record" entries to the end
+        for (int sft = 0; sft < bits; sft += 8) passes.push_back({0, 0, sft, std::min(8, bits - sft), 0});
+        passes.push_back({0, 0, 56, 8, 0});
         sort_records(ctx, 1, rec.p, rtmp.p, ids.as<uint32_t>(), itmp.as<uint32_t>(), 2 * NU, passes);
-        std::vector<uint64_t> hk(2 * NU);
-        std::vector<uint32_t> he(2 * NU);
-        BBK_HIP(hipMemcpyAsync(hk.data(), rec.p, 2 * NU * 8, hipMemcpyDeviceToHost, ctx->stream));
-        BBK_HIP(hipMemcpyAsync(he.data(), ids.p, 2 * NU * 4, hipMemcpyDeviceToHost, ctx->stream));
-        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        if (NC == 0) {
+            KernelTimer t(ctx, "links", 0);
+            DevBuf lcnt((2 * NU + 1) * 8), nv(16);
+            BBK_HIP(hipMemsetAsync(nv.p, 0, 16, ctx->stream));
+            hipLaunchKernelGGL((k_links<false>), dim3((unsigned)((2 * NU + 255) / 256)), dim3(256), 0, ctx->stream,
+                               rec.as<uint64_t>(), ids.as<uint32_t>(), 2 * NU, selfc.as<uint8_t>(), lcnt.as<uint64_t>(),
+                               (const uint64_t *)nullptr, (uint32_t *)nullptr, nv.as<unsigned long long>());
+            check_launch("k_links<count>");
+            const uint64_t NL = exclusive_scan_u64(ctx, lcnt.as<uint64_t>(), lcnt.as<uint64_t>(), 2 * NU);
+            DevBuf dl(NL * 8 + 16);
+            hipLaunchKernelGGL((k_links<true>), dim3((unsigned)((2 * NU + 255) / 256)), dim3(256), 0, ctx->stream,
+                               rec.as<uint64_t>(), ids.as<uint32_t>(), 2 * NU, selfc.as<uint8_t>(), (uint64_t *)nullptr,
+                               lcnt.as<uint64_t>(), dl.as<uint32_t>(), (unsigned long long *)nullptr);
+            check_launch("k_links<write>");
+            unsigned long long hv = 0;
+            d2h(ctx, &hv, nv.p, 8);
+            U.links.resize(2 * NL);
+            if (NL) d2h_big(ctx, U.links.data(), dl.p, NL * 8);
+            U.n = NU;
+            U.n_loops = 0;
+            U.n_vertices = hv;
+            U.n_links = NL;
+            return;
+        }
+        raw_vector<uint64_t> hk(2 * NU);
+        raw_vector<uint32_t> he(2 * NU);
+        d2h_big(ctx, hk.data(), rec.p, 2 * NU * 8);
+        d2h_big(ctx, he.data(), ids.p, 2 * NU * 4);
         recs.reserve(2 * NU);
         for (uint64_t r = 0; r < 2 * NU; ++r) {
             if (hk[r] == ~0ull) break;
@@ -370,11 +461,6 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     uoff.release();
 
     // ---- perfect loops: leftover non-junction k-mers (CollectLoops :308-344), walked on the host
-    DevBuf flag((n + 1) * 8);
-    hipLaunchKernelGGL(k_loop_candidates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       x->masks.as<uint8_t>(), visited.as<uint8_t>(), n, flag.as<uint64_t>());
-    check_launch("k_loop_candidates");
-    const uint64_t NC = exclusive_scan_u64(ctx, flag.as<uint64_t>(), flag.as<uint64_t>(), n);
     uint64_t n_paths = NU, n_loops = 0;
     if (NC) {
         LoopTable T;
@@ -507,16 +593,14 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
                 if (!((b_start && !b_rc) || (!b_start && b_rc))) continue;  // outgoing
                 const uint32_t eb = recs[b].edge;
                 const uint32_t ob = (b_start || selfconj[eb]) ? 1u : 0u;
-                U.links.push_back(ea);
-                U.links.push_back(oa);
-                U.links.push_back(eb);
-                U.links.push_back(ob);
+                U.links.push_back((ea << 1) | oa);
+                U.links.push_back((eb << 1) | ob);
             }
         }
         p = q;
     }
     U.n_vertices = nv;
-    U.n_links = U.links.size() / 4;
+    U.n_links = U.links.size() / 2;
 }
 
 unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsigned k, uint64_t n, DevBuf &prefix);
@@ -638,7 +722,12 @@ int bbk_unitigs_export(bbk_ctx *ctx, const bbk_unitigs *u, char *h_bases, uint64
 int bbk_unitigs_export_links(bbk_ctx *ctx, const bbk_unitigs *u, uint32_t *h_links) {
     return guarded([&] {
         BBK_REQUIRE(ctx && u && (u->links.empty() || h_links), BBK_ERR_ARG, "bbk_unitigs_export_links: NULL argument");
-        if (!u->links.empty()) memcpy(h_links, u->links.data(), u->links.size() * sizeof(uint32_t));
+        for (uint64_t l = 0; l < u->n_links; ++l) {
+            h_links[4 * l] = u->links[2 * l] >> 1;
+            h_links[4 * l + 1] = u->links[2 * l] & 1u;
+            h_links[4 * l + 2] = u->links[2 * l + 1] >> 1;
+            h_links[4 * l + 3] = u->links[2 * l + 1] & 1u;
+        }
     });
 }
 
@@ -653,20 +742,65 @@ static size_t fmt_u64(char *dst, uint64_t v) {
     return n;
 }
 
+static inline size_t dec_len(uint64_t v) {
+    size_t n = 1;
+    while (v >= 10) {
+        v /= 10;
+        ++n;
+    }
+    return n;
+}
+
+// parallel positional writes of one buffer (tmpfs / NVMe scale with writers; a single fwrite of
+// 1.5 GB is a third of the whole GFA time otherwise)
+// host worker threads for text formatting / file writes: the box may expose hundreds of logical CPUs
+// of which only a share is ours
+static int host_threads() { return std::max(1, std::min(omp_get_max_threads(), 32)); }
+
+static bool pwrite_all(int fd, const char *buf, size_t bytes, off_t base) {
+    const size_t chunk = 16ull << 20;
+    const size_t nchunks = (bytes + chunk - 1) / chunk;
+    bool ok = true;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads())
+    for (size_t c = 0; c < nchunks; ++c) {
+        size_t off = c * chunk;
+        const size_t end = std::min(bytes, off + chunk);
+        while (off < end) {
+            const ssize_t w = pwrite(fd, buf + off, end - off, base + (off_t)off);
+            if (w <= 0) {
+#pragma omp atomic write
+                ok = false;
+                break;
+            }
+            off += (size_t)w;
+        }
+    }
+    return ok;
+}
+
 int bbk_unitigs_write_gfa(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) {
     return guarded([&] {
         BBK_REQUIRE(ctx && u && path, BBK_ERR_ARG, "bbk_unitigs_write_gfa: NULL argument");
         // S\t<id>\t<seq>\tDP:f:<cov>\tKC:i:<kc>\n with id = 3 + 2i (graph_core.hpp:228; edge i gets
         // min_id + 2i, debruijn_graph_constructor.hpp:457-458); coverage is 0 without -c.
         const uint64_t n = u->n;
-        std::vector<uint64_t> pos(n + 1, 0);
+        const bool verbose = getenv("BBK_VERBOSE") != nullptr;
+        double t_prev = omp_get_wtime();
+        auto lap = [&](const char *what) {
+            if (verbose) {
+                const double t = omp_get_wtime();
+                fprintf(stderr, "[bbk] write_gfa %-10s %.3f s\n", what, t - t_prev);
+                t_prev = t;
+            }
+        };
+        raw_vector<uint64_t> pos(n + 1);
         // per-segment tail "\tDP:f:<float(KC/(len-k))>\tKC:i:<KC>\n": default ostream formatting of a float
         // is %g with 6 significant digits (gfa_writer.cpp:18-25; coverage = raw / length, coverage.hpp:58-64)
         std::vector<std::string> tails;
         static const char tail0[] = "\tDP:f:0\tKC:i:0\n";
         if (u->has_cov) {
             tails.resize(n);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(host_threads())
             for (uint64_t i = 0; i < n; ++i) {
                 const uint64_t len = u->offsets[i + 1] - u->offsets[i];
                 const double cov = (double)u->kc[i] / (double)(len - u->k);
@@ -675,14 +809,37 @@ int bbk_unitigs_write_gfa(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) 
                 tails[i] = b;
             }
         }
+        // line lengths -> offsets (two-level parallel prefix sum)
+        auto prefix_sum = [](raw_vector<uint64_t> &v, uint64_t cnt) {  // v[i+1] holds the length of item i; v[0] = 0
+            const int T = host_threads();
+            std::vector<uint64_t> part((size_t)T + 1, 0);
+#pragma omp parallel num_threads(T)
+            {
+                const int t = omp_get_thread_num();
+                const uint64_t lo = cnt * (uint64_t)t / T, hi = cnt * (uint64_t)(t + 1) / T;
+                uint64_t sacc = 0;
+                for (uint64_t i = lo; i < hi; ++i) sacc += v[i + 1];
+                part[(size_t)t + 1] = sacc;
+#pragma omp barrier
+#pragma omp single
+                for (int j = 0; j < T; ++j) part[(size_t)j + 1] += part[(size_t)j];
+                uint64_t run = part[(size_t)t];
+                for (uint64_t i = lo; i < hi; ++i) {
+                    run += v[i + 1];
+                    v[i + 1] = run;
+                }
+            }
+        };
+        pos[0] = 0;
+#pragma omp parallel for schedule(static) num_threads(host_threads())
         for (uint64_t i = 0; i < n; ++i) {
-            char tmp[24];
-            const size_t idl = fmt_u64(tmp, 3 + 2 * i);
             const size_t tl = u->has_cov ? tails[i].size() : sizeof(tail0) - 1;
-            pos[i + 1] = pos[i] + 2 + idl + 1 + (u->offsets[i + 1] - u->offsets[i]) + tl;
+            pos[i + 1] = 2 + dec_len(3 + 2 * i) + 1 + (u->offsets[i + 1] - u->offsets[i]) + tl;
         }
-        std::vector<char> buf(pos[n]);
-#pragma omp parallel for schedule(static)
+        prefix_sum(pos, n);
+        lap("S-sizes");
+        raw_vector<char> buf(pos[n]);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
         for (uint64_t i = 0; i < n; ++i) {
             char *d = buf.data() + pos[i];
             *d++ = 'S';
@@ -695,29 +852,42 @@ int bbk_unitigs_write_gfa(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) 
             if (u->has_cov) memcpy(d, tails[i].data(), tails[i].size());
             else memcpy(d, tail0, sizeof(tail0) - 1);
         }
-        FILE *f = fopen(path, "wb");
-        BBK_REQUIRE(f != nullptr, BBK_ERR_IO, "cannot open %s for writing", path);
-        bool ok = buf.empty() || fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        lap("S-format");
         // L\t<e1>\t<+|->\t<e2>\t<+|->\t<k>M\n
-        std::string lines;
-        lines.reserve(1 << 20);
-        char num[24];
-        for (uint64_t l = 0; l < u->n_links && ok; ++l) {
-            const uint32_t *r = &u->links[4 * l];
-            lines += "L\t";
-            lines.append(num, fmt_u64(num, 3 + 2 * (uint64_t)r[0]));
-            lines += r[1] ? "\t+\t" : "\t-\t";
-            lines.append(num, fmt_u64(num, 3 + 2 * (uint64_t)r[2]));
-            lines += r[3] ? "\t+\t" : "\t-\t";
-            lines.append(num, fmt_u64(num, u->k));
-            lines += "M\n";
-            if (lines.size() > (1u << 20)) {
-                ok = fwrite(lines.data(), 1, lines.size(), f) == lines.size();
-                lines.clear();
-            }
+        const uint64_t nl = u->n_links;
+        const size_t kl = dec_len(u->k);
+        raw_vector<uint64_t> lpos(nl + 1);
+        lpos[0] = 0;
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+        for (uint64_t l = 0; l < nl; ++l)
+            lpos[l + 1] = 2 + dec_len(3 + 2 * (uint64_t)(u->links[2 * l] >> 1)) + 3 +
+                          dec_len(3 + 2 * (uint64_t)(u->links[2 * l + 1] >> 1)) + 3 + kl + 2;
+        prefix_sum(lpos, nl);
+        raw_vector<char> lbuf(lpos[nl]);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+        for (uint64_t l = 0; l < nl; ++l) {
+            char *d = lbuf.data() + lpos[l];
+            const uint32_t a = u->links[2 * l], b2 = u->links[2 * l + 1];
+            *d++ = 'L';
+            *d++ = '\t';
+            d += fmt_u64(d, 3 + 2 * (uint64_t)(a >> 1));
+            *d++ = '\t';
+            *d++ = (a & 1u) ? '+' : '-';
+            *d++ = '\t';
+            d += fmt_u64(d, 3 + 2 * (uint64_t)(b2 >> 1));
+            *d++ = '\t';
+            *d++ = (b2 & 1u) ? '+' : '-';
+            *d++ = '\t';
+            d += fmt_u64(d, u->k);
+            *d++ = 'M';
+            *d++ = '\n';
         }
-        if (ok && !lines.empty()) ok = fwrite(lines.data(), 1, lines.size(), f) == lines.size();
-        const int cl = fclose(f);
+        lap("L-format");
+        const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        BBK_REQUIRE(fd >= 0, BBK_ERR_IO, "cannot open %s for writing", path);
+        bool ok = pwrite_all(fd, buf.data(), buf.size(), 0) && pwrite_all(fd, lbuf.data(), lbuf.size(), (off_t)buf.size());
+        const int cl = close(fd);
+        lap("pwrite");
         BBK_REQUIRE(ok && cl == 0, BBK_ERR_IO, "short write to %s", path);
     });
 }
