@@ -771,6 +771,105 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
     if (tid == 0) A.dcount[b] = total;
 }
 
+// Same idea for wider keys: the bucket's keys are staged in LDS and the table holds record INDICES
+// (32-bit ds_cmpst); a probe that finds a different index compares the two keys.  All keys are in
+// LDS before the first insertion, so there is no partially written slot to race with.
+constexpr int kHashIdxThreads = 512;
+constexpr int kHashIdxItems = 8;                        // 512 x 8 = 4096 records per bucket
+constexpr uint32_t kHashIdxCap = kHashIdxThreads * kHashIdxItems;
+constexpr uint32_t kHashIdxSlots = 8192;
+
+template <int W, int OP>
+__global__ __launch_bounds__(kHashIdxThreads) void k_bucket_hashidx(Key<W> *__restrict__ buf,
+                                                                   uint32_t *__restrict__ vals, BucketArgs A) {
+    constexpr bool IN_VAL = OP >= 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *pay = tab + kHashIdxSlots;
+    uint32_t *scan_tmp = pay + (OP != 0 ? kHashIdxSlots : 0);
+    Key<W> *skeys = reinterpret_cast<Key<W> *>(scan_tmp + 32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = A.bucket_ids ? A.bucket_ids[blockIdx.x] : blockIdx.x;
+    const uint32_t start = A.boff[b];
+    const uint32_t n = A.boff[b + 1] - start;
+    if (n == 0) {
+        if (tid == 0) A.dcount[b] = 0;
+        return;
+    }
+    if (n > kHashIdxCap) {
+        if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
+        return;
+    }
+    constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    for (uint32_t s = tid; s < kHashIdxSlots; s += kHashIdxThreads) {
+        tab[s] = EMPTY;
+        if (OP != 0) pay[s] = 0;
+    }
+    uint32_t vv[kHashIdxItems];
+#pragma unroll
+    for (int i = 0; i < kHashIdxItems; ++i) {
+        const uint32_t p = (uint32_t)(i * kHashIdxThreads + tid);
+        vv[i] = 0;
+        if (p < n) {
+            key_store<W>(&skeys[p], key_load<W>(&buf[start + p]));
+            if (IN_VAL) vv[i] = vals[start + p];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kHashIdxItems; ++i) {
+        const uint32_t p = (uint32_t)(i * kHashIdxThreads + tid);
+        if (p < n) {
+            const Key<W> key = key_load<W>(&skeys[p]);
+            // bits of the hash other than the ones the partition consumed (its top ~20)
+            uint32_t slot = (part_hash32<W>(key) * 0x9E3779B1u >> 7) & (kHashIdxSlots - 1);
+            for (;;) {
+                const uint32_t old = atomicCAS(&tab[slot], EMPTY, p);
+                if (old == EMPTY) break;
+                if (key_eq<W>(key_load<W>(&skeys[old]), key)) break;
+                slot = (slot + 1) & (kHashIdxSlots - 1);
+            }
+            if (OP == 1) atomicAdd(&pay[slot], 1u);
+            else if (OP == 2) atomicAdd(&pay[slot], vv[i]);
+            else if (OP == 3) atomicOr(&pay[slot], vv[i]);
+        }
+    }
+    __syncthreads();
+    constexpr int SPT = kHashIdxSlots / kHashIdxThreads;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) cnt += tab[tid * SPT + j] != EMPTY ? 1u : 0u;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        uint32_t t = __shfl_up(incl, dd, 64);
+        if (lane >= dd) incl += t;
+    }
+    if (lane == 63) scan_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (int j = 0; j < kHashIdxThreads / 64; ++j) {
+        if (j < wave) wbase += scan_tmp[j];
+        total += scan_tmp[j];
+    }
+    uint32_t o = start + wbase + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+        const uint32_t idx = tab[tid * SPT + j];
+        if (idx != EMPTY) {
+            key_store<W>(&buf[o], key_load<W>(&skeys[idx]));
+            if (OP != 0) vals[o] = pay[tid * SPT + j];
+            ++o;
+        }
+    }
+    if (tid == 0) A.dcount[b] = total;
+}
+
+template <int W, int OP>
+static size_t bucket_hashidx_smem() {
+    return 4 * kHashIdxSlots + (OP != 0 ? 4 * kHashIdxSlots : 0) + 128 + (size_t)W * 8 * kHashIdxCap;
+}
+
 template <int OP>
 static size_t bucket_hash_smem() {
     return sizeof(unsigned long long) * kHashSlots + (OP != 0 ? 4 * kHashSlots : 0) + 64;
@@ -880,10 +979,37 @@ struct MsdRunner {
 
     // unsorted dedup is enough when a later stage sorts the distinct records (HASH mode)
     bool use_hash_dedup() const { return W == 1 && dmode == MSD_HASH && 2 * k < 64; }
+    bool use_hashidx_dedup() const { return W >= 2 && dmode == MSD_HASH; }
+    // records a first-pass bucket kernel can hold
+    uint32_t bucket_cap() const { return use_hashidx_dedup() ? kHashIdxCap : kBucketCap; }
+
+    template <int OP>
+    void launch_bucket_hashidx(uint32_t nblocks, Key<W> *buf, uint32_t *vals, BucketArgs A, double bytes) {
+        if constexpr (W >= 2) {
+            if (nblocks == 0) return;
+            const size_t sm = bucket_hashidx_smem<W, OP>();
+            auto fn = k_bucket_hashidx<W, OP>;
+            BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)sm));
+            KernelTimer t(ctx, "lds_dedup", bytes);
+            hipLaunchKernelGGL(fn, dim3(nblocks), dim3(kHashIdxThreads), sm, ctx->stream, buf, vals, A);
+            check_launch("k_bucket_hashidx");
+        }
+    }
 
     template <int NT>
-    void bucket_dispatch(uint32_t nblocks, Key<W> *buf, uint32_t *vals, BucketArgs A, double bytes) {
-        if (NT == kBktThreads && use_hash_dedup()) {
+    void bucket_dispatch(uint32_t nblocks, Key<W> *buf, uint32_t *vals, BucketArgs A, double bytes,
+                         bool allow_hash = true) {
+        if (allow_hash && NT == kBktThreads && use_hashidx_dedup()) {
+            switch (op) {
+                case MSD_OP_NONE: launch_bucket_hashidx<0>(nblocks, buf, vals, A, bytes); return;
+                case MSD_OP_COUNT: launch_bucket_hashidx<1>(nblocks, buf, vals, A, bytes); return;
+                case MSD_OP_SUM: launch_bucket_hashidx<2>(nblocks, buf, vals, A, bytes); return;
+                case MSD_OP_OR: launch_bucket_hashidx<3>(nblocks, buf, vals, A, bytes); return;
+                default: BBK_REQUIRE(false, BBK_ERR_ARG, "bad reduce op");
+            }
+        }
+        if (allow_hash && NT == kBktThreads && use_hash_dedup()) {
             switch (op) {
                 case MSD_OP_NONE: launch_bucket_hash<0>(nblocks, buf, vals, A, bytes); return;
                 case MSD_OP_COUNT: launch_bucket_hash<1>(nblocks, buf, vals, A, bytes); return;
@@ -936,7 +1062,7 @@ struct MsdRunner {
                     (unsigned long long)N);
 
         // ---- bin plan: nb1 (power of two) level-1 bins; level-2 bin counts are chosen per segment below
-        const double target = kBucketFill * kBucketCap;
+        const double target = kBucketFill * bucket_cap();
         const double want = std::max(1.0, std::ceil((double)N / target));
         uint32_t nb1 = 1;
         int b1 = 0;
@@ -1059,19 +1185,26 @@ struct MsdRunner {
         BBK_HIP(hipStreamSynchronize(ctx->stream));
         std::vector<uint32_t> big;
         uint64_t big_rec = 0;
-        // (the 512-thread variant needs 2 x CAP records in LDS: only the 8-byte keys fit in 160 KiB)
-        const bool big_ok = bucket_smem<W, 2 * kBktThreads, kBucketItems, 3>() <= 160 * 1024;
+        // second chance: 8-byte keys -> the 512-thread sorting kernel (2 x 6144 records); wider keys whose
+        // first pass was the 4096-record hash kernel -> the 256-thread sorting kernel (6144 records)
+        const uint32_t cap2 = (W == 1) ? kBucketCapBig
+                                       : ((use_hashidx_dedup() && bucket_smem<W, kBktThreads, kBucketItems, 3>() <= 160 * 1024)
+                                              ? kBucketCap : 0u);
         for (uint32_t b = 0; b < nbuckets; ++b)
-            if (big_ok && hd[b] == 0xFFFFFFFFu && hb[b + 1] - hb[b] <= kBucketCapBig) {
+            if (hd[b] == 0xFFFFFFFFu && hb[b + 1] - hb[b] <= cap2) {
                 big.push_back(b);
                 big_rec += hb[b + 1] - hb[b];
             }
-        if constexpr (W == 1) if (!big.empty()) {
+        if (!big.empty()) {
             DevBuf ids(big.size() * 4);
             BBK_HIP(hipMemcpyAsync(ids.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             BucketArgs A2{boff.as<uint32_t>(), dcount.as<uint32_t>(), ids.as<uint32_t>(), (int)k};
-            bucket_dispatch<2 * kBktThreads>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2,
-                                             (double)big_rec * (rec + (has_val ? 4 : 0)));
+            const double b2 = (double)big_rec * (rec + (has_val ? 4 : 0));
+            if constexpr (W == 1)
+                bucket_dispatch<2 * kBktThreads>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2);
+            else
+                bucket_dispatch<kBktThreads>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2,
+                                             /*allow_hash=*/false);
             BBK_HIP(hipMemcpyAsync(hd.data(), dcount.p, (size_t)nbuckets * 4, hipMemcpyDeviceToHost, ctx->stream));
             BBK_HIP(hipStreamSynchronize(ctx->stream));
         }
@@ -1085,7 +1218,7 @@ struct MsdRunner {
             uint32_t mx = 0;
             for (uint32_t b = 0; b < nbuckets; ++b) mx = std::max(mx, hb[b + 1] - hb[b]);
             fprintf(stderr, "[bbk] msd mode=%d N=%llu nb1=%u buckets=%u max_bucket=%u cap=%u big=%zu lsd=%llu (%llu rec)\n",
-                    dmode, (unsigned long long)N, nb1, nbuckets, mx, kBucketCap, big.size(), (unsigned long long)novf,
+                    dmode, (unsigned long long)N, nb1, nbuckets, mx, bucket_cap(), big.size(), (unsigned long long)novf,
                     (unsigned long long)ovf_rec);
         }
         if (novf > 256 || ovf_rec > N / 4) return false;
