@@ -149,6 +149,9 @@ int bbk_unitigs_export_links(bbk_ctx *ctx, const bbk_unitigs *u, uint32_t *h_lin
  * projects/gbuilder/main.cpp:183-192. */
 int bbk_unitigs_write_gfa(bbk_ctx *ctx, const bbk_unitigs *u, const char *path);
 int bbk_unitigs_write_fasta(bbk_ctx *ctx, const bbk_unitigs *u, const char *path);
+/* FASTG as FastgWriter::WriteSegmentsAndLinks (common/io/graph/fastg_writer.cpp:20-47): every edge and its
+ * conjugate, header = EDGE_<id>_length_<len>_cov_<cov>['] : successors ; */
+int bbk_unitigs_write_fastg(bbk_ctx *ctx, const bbk_unitigs *u, const char *path);
 void bbk_unitigs_free(bbk_unitigs *u);
 
 #ifdef __cplusplus

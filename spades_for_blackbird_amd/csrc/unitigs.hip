@@ -892,6 +892,91 @@ int bbk_unitigs_write_gfa(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) 
     });
 }
 
+int bbk_unitigs_write_fastg(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && u && path, BBK_ERR_ARG, "bbk_unitigs_write_fastg: NULL argument");
+        // FastgWriter::WriteSegmentsAndLinks (common/io/graph/fastg_writer.cpp:20-47): one FASTA record per
+        // edge AND per conjugate edge; header = name, ':' + comma-separated names of the edges leaving its end
+        // vertex (a std::set, i.e. sorted as strings), ';'.  Names are BasicNamingF
+        // (io/utils/edge_namer.hpp:33-38): EDGE_<id>_length_<len>_cov_<to_string(cov)>, a conjugate edge is
+        // the canonical name + "'" (extended_namer_, fastg_writer.hpp:30).  Record order in the reference
+        // follows its vertex numbering (BooPHF order); here: edge id order, the edge before its conjugate.
+        const uint64_t n = u->n;
+        std::vector<uint8_t> selfconj(n, 0);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+        for (uint64_t i = 0; i < n; ++i) {
+            const char *sq = u->bases.data() + u->offsets[i];
+            const uint64_t len = u->offsets[i + 1] - u->offsets[i];
+            bool sc = true;
+            for (uint64_t a = 0; a < len && sc; ++a) {
+                const char c = sq[len - 1 - a];
+                const char r = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+                sc = sq[a] == r;
+            }
+            selfconj[i] = sc;
+        }
+        auto flip = [&](uint32_t t) { return selfconj[t >> 1] ? t : (t ^ 1u); };
+        // adjacency of oriented edges: a stored link x -> y also means rc(y) -> rc(x)
+        std::vector<std::pair<uint32_t, uint32_t>> adj;
+        adj.reserve(2 * u->n_links);
+        for (uint64_t l = 0; l < u->n_links; ++l) {
+            const uint32_t x = u->links[2 * l], y = u->links[2 * l + 1];
+            adj.emplace_back(x, y);
+            adj.emplace_back(flip(y), flip(x));
+        }
+        std::sort(adj.begin(), adj.end());
+        adj.erase(std::unique(adj.begin(), adj.end()), adj.end());
+        auto name = [&](uint32_t t) {
+            const uint64_t i = t >> 1;
+            const uint64_t len = u->offsets[i + 1] - u->offsets[i];
+            const double cov = u->has_cov ? (double)u->kc[i] / (double)(len - u->k) : 0.0;
+            std::string s = "EDGE_" + std::to_string(3 + 2 * i) + "_length_" + std::to_string(len) + "_cov_" +
+                            std::to_string(cov);
+            if (!(t & 1u)) s += "'";
+            return s;
+        };
+        FILE *f = fopen(path, "wb");
+        BBK_REQUIRE(f != nullptr, BBK_ERR_IO, "cannot open %s for writing", path);
+        bool ok = true;
+        std::string seq, hdr;
+        size_t ai = 0;
+        for (uint64_t i = 0; i < n && ok; ++i) {
+            for (int o = 1; o >= 0 && ok; --o) {
+                if (o == 0 && selfconj[i]) continue;
+                const uint32_t t = (uint32_t)(i << 1) | (uint32_t)o;
+                // successors of t: adj is sorted by (from, to); orientation '-' (0) sorts before '+' (1)
+                auto lo = std::lower_bound(adj.begin(), adj.end(), std::make_pair(t, 0u));
+                std::vector<std::string> next;
+                for (auto it = lo; it != adj.end() && it->first == t; ++it) next.push_back(name(it->second));
+                std::sort(next.begin(), next.end());
+                hdr = ">" + name(t);
+                const char *delim = ":";
+                for (const std::string &nx : next) {
+                    hdr += delim;
+                    hdr += nx;
+                    delim = ",";
+                }
+                hdr += ";\n";
+                const char *sq = u->bases.data() + u->offsets[i];
+                const uint64_t len = u->offsets[i + 1] - u->offsets[i];
+                seq.assign(sq, sq + len);
+                if (o == 0) {
+                    std::reverse(seq.begin(), seq.end());
+                    for (char &c : seq) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+                }
+                ok = fwrite(hdr.data(), 1, hdr.size(), f) == hdr.size();
+                for (uint64_t cur = 0; cur < len && ok; cur += 60) {
+                    const uint64_t w = std::min<uint64_t>(60, len - cur);
+                    ok = fwrite(seq.data() + cur, 1, w, f) == w && fputc('\n', f) != EOF;
+                }
+            }
+        }
+        (void)ai;
+        const int cl = fclose(f);
+        BBK_REQUIRE(ok && cl == 0, BBK_ERR_IO, "short write to %s", path);
+    });
+}
+
 int bbk_unitigs_write_fasta(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) {
     return guarded([&] {
         BBK_REQUIRE(ctx && u && path, BBK_ERR_ARG, "bbk_unitigs_write_fasta: NULL argument");

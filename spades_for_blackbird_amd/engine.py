@@ -22,7 +22,7 @@ SYMBOLS = [
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_free",
     "bbk_unitigs_build", "bbk_unitigs_add_coverage", "bbk_unitigs_export_kc", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
     "bbk_unitigs_vertices", "bbk_unitigs_links", "bbk_unitigs_export", "bbk_unitigs_export_links",
-    "bbk_unitigs_write_gfa", "bbk_unitigs_write_fasta", "bbk_unitigs_free",
+    "bbk_unitigs_write_gfa", "bbk_unitigs_write_fasta", "bbk_unitigs_write_fastg", "bbk_unitigs_free",
 ]
 
 
@@ -98,6 +98,7 @@ def load_library():
         L.bbk_unitigs_export_links.argtypes = [vp, vp, vp]
         L.bbk_unitigs_write_gfa.argtypes = [vp, vp, C.c_char_p]
         L.bbk_unitigs_write_fasta.argtypes = [vp, vp, C.c_char_p]
+        L.bbk_unitigs_write_fastg.argtypes = [vp, vp, C.c_char_p]
         L.bbk_unitigs_free.argtypes = [vp]
     _LIB = L
     return L
@@ -373,6 +374,9 @@ class Unitigs(_Handle):
 
     def write_gfa(self, path):
         _check(self._L.bbk_unitigs_write_gfa(self.ctx._h, self._h, path.encode()))
+
+    def write_fastg(self, path):
+        _check(self._L.bbk_unitigs_write_fastg(self.ctx._h, self._h, path.encode()))
 
     def write_fasta(self, path):
         _check(self._L.bbk_unitigs_write_fasta(self.ctx._h, self._h, path.encode()))

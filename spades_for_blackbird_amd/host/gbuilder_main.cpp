@@ -4,7 +4,7 @@
 // and the same flow (:103-237): reads -> extension index -> unbranching paths + loops ->
 // unitig FASTA or graph -> GFA, with every step behind the C ABI (include/bbk.h).
 // -t/-tmp-dir/-b are accepted for compatibility (no temp files, no per-thread buffers here).
-// --fastg and --spades are SURVEY 8(f) "next" rows and are refused with a clear message.
+// --spades (binary graph) is a SURVEY 8(f) "next" row and is refused with a clear message.
 #include <cstring>
 #include <string>
 #include <vector>
@@ -71,8 +71,8 @@ int main(int argc, char **argv) {
         case GFA: info("Producing graph in GFA1 format"); break;
         case SPADES: info("Producing graph in SPAdes internal format"); break;
     }
-    if (mode == FASTG || mode == SPADES)
-        fatal("this build writes --unitigs and --gfa; FASTG / SPAdes-binary output is not implemented yet");
+    if (mode == SPADES)
+        fatal("this build writes --unitigs, --gfa and --fastg; the SPAdes-binary graph format is not implemented yet");
     if (coverage && mode == UNITIGS) info("Note: -c has no effect on --unitigs output");
 
     // LoadDataset (:89-101)
@@ -118,7 +118,8 @@ int main(int argc, char **argv) {
             info("Filling coverage and flanking coverage from PHM");
         }
         info("Saving graph to %s", outfile.c_str());
-        check(bbk_unitigs_write_gfa(ctx, u, outfile.c_str()), "bbk_unitigs_write_gfa");
+        if (mode == GFA) check(bbk_unitigs_write_gfa(ctx, u, outfile.c_str()), "bbk_unitigs_write_gfa");
+        else check(bbk_unitigs_write_fastg(ctx, u, outfile.c_str()), "bbk_unitigs_write_fastg");
     }
     bbk_unitigs_free(u);
     bbk_extindex_free(ext);

@@ -212,3 +212,48 @@ def test_coverage_kat_and_synthetic(ctx, golden, tmp_path):
         u.write_gfa(p)
         exp = O.ExtIndex(reads, k, 2).unitigs().gfa(with_cov=True)[0]
         assert gfa_canon.canon_md5(open(p).read(), with_kc=True) == gfa_canon.canon_md5(exp, with_kc=True)
+
+
+def test_fastg_structure(ctx, tmp_path):
+    """FASTG (gbuilder --fastg): no reference fixture ships for it ("parity unpinned" for the exact
+    text); checked structurally against the GFA of the same graph: every edge and its conjugate once,
+    successor lists = the link set closed under reverse complement, names per BasicNamingF."""
+    reads = synth_reads(600, read_len=100, genome_len=2500, sub_rate=0.01, seed=77)
+    k = 21
+    r = ctx.reads_from_ascii(reads)
+    u = ctx.unitigs(ctx.extindex(r, k))
+    p = str(tmp_path / "g.fastg")
+    u.write_fastg(p)
+    seqs = u.sequences()
+    recs = {}
+    name = None
+    for line in open(p):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            assert line.endswith(";")
+            head = line[1:-1]
+            name, _, succ = head.partition(":")
+            recs[name] = [succ.split(",") if succ else [], ""]
+        else:
+            recs[name][1] += line
+    n_self = sum(1 for s in seqs if s == rc(s))
+    assert len(recs) == 2 * len(seqs) - n_self
+
+    def nm(i, plus):
+        return "EDGE_%d_length_%d_cov_0.000000%s" % (3 + 2 * i, len(seqs[i]), "" if plus else "'")
+    for i, s in enumerate(seqs):
+        assert recs[nm(i, True)][1] == s
+        if s != rc(s):
+            assert recs[nm(i, False)][1] == rc(s)
+    exp = set()
+    for a, oa, b, ob in u.links():
+        exp.add((nm(a, oa), nm(b, ob)))
+        fa = oa if seqs[a] == rc(seqs[a]) else 1 - oa
+        fb = ob if seqs[b] == rc(seqs[b]) else 1 - ob
+        exp.add((nm(b, fb), nm(a, fa)))
+    got = set((x, y) for x, (succ, _) in recs.items() for y in succ)
+    assert got == exp
+    for x, y in got:
+        assert recs[x][1][-k:] == recs[y][1][:k]
+    for x, (succ, _) in recs.items():
+        assert succ == sorted(succ)
