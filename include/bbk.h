@@ -90,11 +90,16 @@ void bbk_reads_free(bbk_reads *r);
 #define BBK_CANONICAL 2u    /* only IsMinimal k-mers (utils/ph_map/storing_traits.hpp:90-101), as the
                                gbuilder splitters use (kmer_splitters.hpp:25-41) */
 #define BBK_WITH_COUNTS 4u  /* keep multiplicities (occurrences over reads + rc(reads)) */
+#define BBK_UNSORTED 8u     /* distinct set only, internal (hash-bucket) order: enough for the owner partition,
+                               bbk_kmerset_both_strands and a later bbk_kmerset_from_device; skips the sort */
 int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, bbk_kmerset **out);
 /* Sort + unique an array of k-mer records already in HBM (n records of bbk_words(k) u64 each,
  * optional u32 multiplicities that are summed).  Used after the multi-GPU exchange. */
 int bbk_kmerset_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, unsigned k,
                             bbk_kmerset **out);
+/* same with flags: BBK_UNSORTED deduplicates only (hash-bucket order) */
+int bbk_kmerset_from_device_ex(bbk_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, unsigned k,
+                               unsigned flags, bbk_kmerset **out);
 /* canon U rc(canon): the both-strand set of spades-kmercount from a BBK_CANONICAL set (each rank
  * applies it to its own shard after the multi-GPU exchange). */
 int bbk_kmerset_both_strands(bbk_ctx *ctx, const bbk_kmerset *canon, bbk_kmerset **out);

@@ -30,18 +30,22 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=None, suffix=""):
+    """extra_flags / suffix build an experimental variant (objects and library get the suffix)."""
+    global LIB
     hipcc = _hipcc()
+    extra_flags = list(extra_flags or [])
+    lib = LIB.replace(".so", suffix + ".so") if suffix else LIB
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, s.replace(".hip", suffix + ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + extra_flags + ["-x", "hip", "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -54,10 +58,12 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-fopenmp", "-o", LIB] + objs)
-    return LIB
+    if jobs or force or _stale(lib, objs):
+        run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-fopenmp", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    extra = [a for a in sys.argv[1:] if a.startswith("-D")]
+    suffix = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--suffix=")), "")
+    print(build(force="--force" in sys.argv, verbose=True, extra_flags=extra, suffix=suffix))

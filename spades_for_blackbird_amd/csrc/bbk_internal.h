@@ -242,6 +242,7 @@ struct bbk_kmerset {
     bbk::DevBuf keys;        // n * W u64, ascending
     bbk::DevBuf counts;      // n u32 (optional)
     bool has_counts = false;
+    bool sorted = true;      // false: distinct but in hash-bucket order (BBK_UNSORTED)
 };
 
 struct bbk_extindex {

@@ -313,6 +313,19 @@ int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, 
                 return;
             }
         }
+        if (canon && (flags & BBK_UNSORTED) && msd_enabled()) {
+            MsdOutput a;
+            if (msd_sort_reduce(ctx, k, MSD_HASH, wc ? MSD_OP_COUNT : MSD_OP_NONE, reads, nullptr, nullptr, 0, false,
+                                a)) {
+                s->instances = a.instances;
+                s->n = a.n;
+                s->sorted = false;
+                s->keys = std::move(a.keys);
+                if (wc) s->counts = std::move(a.vals);
+                *out = s.release();
+                return;
+            }
+        }
         count_canonical(ctx, reads, k, /*with_mask=*/false, wc, ck, cv, D, N);
         s->instances = both ? 2 * N : N;
         if (canon) {
@@ -328,6 +341,11 @@ int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, 
 
 int bbk_kmerset_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, unsigned k,
                             bbk_kmerset **out) {
+    return bbk_kmerset_from_device_ex(ctx, d_keys, d_counts, n, k, 0, out);
+}
+
+int bbk_kmerset_from_device_ex(bbk_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, unsigned k,
+                               unsigned flags, bbk_kmerset **out) {
     return guarded([&] {
         BBK_REQUIRE(ctx && out && (n == 0 || d_keys), BBK_ERR_ARG, "bbk_kmerset_from_device: NULL argument");
         check_k(k);
@@ -346,9 +364,11 @@ int bbk_kmerset_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_coun
         }
         if (msd_enabled()) {
             MsdOutput m;
-            if (msd_sort_reduce(ctx, k, MSD_KEYS, d_counts ? MSD_OP_SUM : MSD_OP_NONE, nullptr, d_keys,
-                                (const uint32_t *)d_counts, n, false, m)) {
+            const bool unsorted = (flags & BBK_UNSORTED) != 0;
+            if (msd_sort_reduce(ctx, k, unsorted ? MSD_HASH : MSD_KEYS, d_counts ? MSD_OP_SUM : MSD_OP_NONE, nullptr,
+                                d_keys, (const uint32_t *)d_counts, n, false, m)) {
                 s->n = m.n;
+                s->sorted = !unsorted;
                 s->keys = std::move(m.keys);
                 if (d_counts) s->counts = std::move(m.vals);
                 *out = s.release();
@@ -401,6 +421,10 @@ uint64_t bbk_kmerset_instances(const bbk_kmerset *s) { return s ? s->instances :
 static void export_ordered(bbk_ctx *ctx, const bbk_kmerset *s, const PassDesc *pd, void *dst_keys, void *dst_counts,
                            uint64_t *h_counts) {
     BBK_HIP(hipSetDevice(ctx->device));
+    // an unsorted set may only be partitioned by owner (order inside a segment is irrelevant there)
+    BBK_REQUIRE(s->sorted || (pd && pd->kind == 2), BBK_ERR_ARG,
+                "this k-mer set was built with BBK_UNSORTED: it can be owner-partitioned, expanded or re-merged, "
+                "not exported in key order");
     const size_t rec = (size_t)s->W * 8;
     if (h_counts && pd) memset(h_counts, 0, pd->nb * sizeof(uint64_t));
     if (s->n == 0) return;

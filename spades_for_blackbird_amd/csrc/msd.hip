@@ -40,10 +40,16 @@ namespace bbk {
 // Partition tile: 8192 records of 8 B (4096 of 16 B) staged in LDS.  From a key array 512 threads x 16
 // items keep the loads wide; from reads (extraction fused: instruction- and latency-bound) the same
 // tile is spread over 1024 threads x 8 items so that a CU holds 16 waves at one workgroup per CU.
-constexpr int part_threads(int src) { return src == 1 ? 1024 : 512; }
+#ifndef BBK_KEYS_TILE
+#define BBK_KEYS_TILE 8192
+#endif
+#ifndef BBK_KEYS_THREADS
+#define BBK_KEYS_THREADS 512
+#endif
+constexpr int part_threads(int src) { return src == 1 ? 1024 : BBK_KEYS_THREADS; }
 template <int W, int SRC>
 struct PartCfg {
-    static constexpr int TILE = (W == 1) ? 8192 : 4096;
+    static constexpr int TILE = (W == 1) ? (SRC == 1 ? 8192 : BBK_KEYS_TILE) : 4096;
     static constexpr int THREADS = part_threads(SRC);
     static constexpr int ITEMS = TILE / THREADS;
 };
@@ -1030,7 +1036,7 @@ struct MsdRunner {
     // returns false if the caller should use the LSD path instead (too much overflow)
     bool run(const bbk_reads *rd, const void *d_keys, const uint32_t *d_vals, uint64_t n_in, bool with_mask,
              MsdOutput &out) {
-        constexpr uint32_t kPartTile = PartCfg<W, 0>::TILE;
+        constexpr uint32_t kPartTileK = PartCfg<W, 0>::TILE, kPartTileR = PartCfg<W, 1>::TILE;
         const bool from_reads = rd != nullptr;
         const bool has_val = with_mask || d_vals != nullptr;
         const size_t rec = (size_t)W * 8;
@@ -1057,7 +1063,8 @@ struct MsdRunner {
             out.vals.alloc(16);
             return true;
         }
-        BBK_REQUIRE(N < (1ull << 32) - kPartTile, BBK_ERR_ARG,
+        const uint32_t kPartTile1 = from_reads ? kPartTileR : kPartTileK;  // level-1 tile of this call
+        BBK_REQUIRE(N < (1ull << 32) - kPartTileK, BBK_ERR_ARG,
                     "batch holds %llu records; a single device batch is limited to 2^32-1 (split the input)",
                     (unsigned long long)N);
 
@@ -1077,12 +1084,12 @@ struct MsdRunner {
         }
         PartLevel L1{1, b1, nb1, dmode, w0bits, nullptr, nullptr};
 
-        const uint32_t ntiles1 = (uint32_t)((N + kPartTile - 1) / kPartTile);
+        const uint32_t ntiles1 = (uint32_t)((N + kPartTile1 - 1) / kPartTile1);
         ReadSrc S{};
         if (from_reads) {
             tile_read.alloc(((size_t)ntiles1 + 2) * sizeof(uint32_t));
             hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1 + 1 + 255) / 256), dim3(256), 0, ctx->stream,
-                               koff.as<uint64_t>(), rd->n, (uint64_t)ntiles1, kPartTile, tile_read.as<uint32_t>());
+                               koff.as<uint64_t>(), rd->n, (uint64_t)ntiles1, kPartTileR, tile_read.as<uint32_t>());
             check_launch("k_tile_reads");
             S = ReadSrc{rd->d_words, rd->d_woff, rd->d_len, koff.as<uint64_t>(), tile_read.as<uint32_t>(), rd->n, (int)k};
         }
@@ -1111,7 +1118,7 @@ struct MsdRunner {
         sbin[0] = 0;
         for (uint32_t b = 0; b < nb1; ++b) {
             off1[b + 1] = off1[b] + h1[b];
-            tstart[b + 1] = tstart[b] + (h1[b] + kPartTile - 1) / kPartTile;
+            tstart[b + 1] = tstart[b] + (h1[b] + kPartTileK - 1) / kPartTileK;
             snb2[b] = (uint32_t)std::min<double>(kMaxBins, std::max(1.0, std::ceil((double)h1[b] / target)));
             sbin[b + 1] = sbin[b] + snb2[b];
         }

@@ -67,13 +67,15 @@ def sharded_count(ctx, reads, k, both_strands=True, group=None):
     world = dist.get_world_size(group)
     nw = E.words(k)
     dev = torch.device("cuda", ctx.device)
-    c = ctx.count(reads, k, E.CANONICAL)
+    # local dedup only (hash-bucket order): the owner partition does not need sorted input
+    c = ctx.count(reads, k, E.CANONICAL | E.UNSORTED)
     send = torch.empty((len(c), nw), dtype=torch.int64, device=dev)
     counts = c.export_by_owner(world, dst_keys=send)
     c.free()
     recv, rcl = exchange_by_owner(send, counts, nw, group)
     torch.cuda.current_stream().synchronize()
-    shard = ctx.kmerset_from_device(recv, sum(rcl), k)
+    # merge-unique of the shard; sorted only if it is the final product
+    shard = ctx.kmerset_from_device(recv, sum(rcl), k, flags=E.UNSORTED if both_strands else 0)
     if not both_strands:
         return shard
     both = shard.both_strands()

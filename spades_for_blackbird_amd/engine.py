@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-BOTH_STRANDS, CANONICAL, WITH_COUNTS = 1, 2, 4
+BOTH_STRANDS, CANONICAL, WITH_COUNTS, UNSORTED = 1, 2, 4, 8
 ORDER_SORTED, ORDER_REFERENCE_BUCKETS16 = 0, 1
 
 # every symbol include/bbk.h declares (checked by tests/test_abi.py)
@@ -16,7 +16,7 @@ SYMBOLS = [
     "bbk_ctx_synchronize", "bbk_ctx_profile_enable", "bbk_ctx_profile_reset", "bbk_ctx_profile_get",
     "bbk_reads_from_ascii", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_count", "bbk_reads_bases",
     "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
-    "bbk_count", "bbk_kmerset_from_device", "bbk_kmerset_both_strands", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k",
+    "bbk_count", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k",
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_free",
@@ -31,7 +31,8 @@ class BBKError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libbbk.so")
+    # BBK_LIB selects an experimental build variant (python -m spades_for_blackbird_amd.build --suffix=...)
+    return os.environ.get("BBK_LIB") or os.path.join(_HERE, "libbbk.so")
 
 
 def load_library():
@@ -66,6 +67,7 @@ def load_library():
     L.bbk_reads_free.argtypes = [vp]
     L.bbk_count.argtypes = [vp, vp, C.c_uint, C.c_uint, C.POINTER(vp)]
     L.bbk_kmerset_from_device.argtypes = [vp, vp, vp, u64, C.c_uint, C.POINTER(vp)]
+    L.bbk_kmerset_from_device_ex.argtypes = [vp, vp, vp, u64, C.c_uint, C.c_uint, C.POINTER(vp)]
     L.bbk_kmerset_both_strands.argtypes = [vp, vp, C.POINTER(vp)]
     L.bbk_words.restype = C.c_uint
     L.bbk_words.argtypes = [C.c_uint]
@@ -194,9 +196,9 @@ class Context:
         _check(self._L.bbk_count(self._h, reads._h, k, flags, C.byref(h)))
         return KMerSet(self, h)
 
-    def kmerset_from_device(self, d_keys, n, k, d_counts=None):
+    def kmerset_from_device(self, d_keys, n, k, d_counts=None, flags=0):
         h = C.c_void_p()
-        _check(self._L.bbk_kmerset_from_device(self._h, _ptr(d_keys), _ptr(d_counts), n, k, C.byref(h)))
+        _check(self._L.bbk_kmerset_from_device_ex(self._h, _ptr(d_keys), _ptr(d_counts), n, k, flags, C.byref(h)))
         return KMerSet(self, h)
 
     def extindex(self, reads, k):

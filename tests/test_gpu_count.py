@@ -183,3 +183,24 @@ def test_high_multiplicity_overflow(ctx):
         exp, expc = O.kmercount(reads, k, 16, 2, with_counts=True)
         got, gotc = gpu_final_kmers(ctx, reads, k, with_counts=True)
         assert np.array_equal(got, exp) and np.array_equal(gotc, expc)
+
+
+def test_unsorted_sets(ctx):
+    """BBK_UNSORTED: dedup only (hash-bucket order) -- same set, may be owner-partitioned, expanded and
+    re-merged, refuses a key-ordered export."""
+    reads = synth_reads(1500, read_len=120, genome_len=8000, seed=9)
+    for k in (21, 33):
+        r = ctx.reads_from_ascii(reads)
+        ref = ctx.count(r, k, B.CANONICAL | B.WITH_COUNTS)
+        rk, rc_ = ref.export(B.ORDER_SORTED, with_counts=True)
+        u = ctx.count(r, k, B.CANONICAL | B.UNSORTED | B.WITH_COUNTS)
+        assert len(u) == len(ref)
+        with pytest.raises(B.BBKError):
+            u.export(B.ORDER_SORTED)
+        part, counts = u.export_by_owner(4)
+        order = np.lexsort([part[:, j] for j in range(part.shape[1] - 1, -1, -1)])
+        assert np.array_equal(part[order], rk)
+        both = u.both_strands()
+        exp, expc = O.kmercount(reads, k, 16, 2, with_counts=True)
+        got, gotc = both.export(B.ORDER_REFERENCE_BUCKETS16, with_counts=True)
+        assert np.array_equal(got, exp) and np.array_equal(gotc, expc)
