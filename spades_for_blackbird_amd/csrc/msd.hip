@@ -77,7 +77,19 @@ struct PartLevel {
     // skewed prefix distribution still gives buckets of the target size) and flat bin base
     const uint32_t *seg_nb2;
     const uint32_t *seg_bin_start;
+    // hash-range pass (inputs above one device batch): only records whose prefix starts with sel_val
+    // (sel_bits bits) take part; the remaining prefix bits drive the bins
+    int sel_bits;
+    uint32_t sel_val;
 };
+
+// applies the range selection: false = the record belongs to another pass; p loses the selection bits
+__device__ inline bool select_prefix(uint32_t &p, const PartLevel &L) {
+    if (L.sel_bits == 0) return true;
+    if ((p >> (32 - L.sel_bits)) != L.sel_val) return false;
+    p <<= L.sel_bits;
+    return true;
+}
 
 // bin of this level inside its segment (nb = bins of the segment at level 2)
 __device__ inline uint32_t bin_of(uint32_t p, const PartLevel &L, uint32_t nb) {
@@ -346,9 +358,12 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
             } else {
                 read_record<W, HAS_VAL>(S, jbase + local, s_rel, r0, nr, rl, keys[i], vals[i]);
             }
-            const uint32_t b = bin_of(prefix_of<W>(keys[i], L.dmode, L.w0bits), L, nb);
-            const uint32_t rank = atomicAdd(&lhist[b], 1u);
-            binrank[i] = (b << 16) | rank;
+            uint32_t pfx = prefix_of<W>(keys[i], L.dmode, L.w0bits);
+            if (select_prefix(pfx, L)) {
+                const uint32_t b = bin_of(pfx, L, nb);
+                const uint32_t rank = atomicAdd(&lhist[b], 1u);
+                binrank[i] = (b << 16) | rank;
+            }
         }
     }
     __syncthreads();
@@ -362,6 +377,7 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
     }
 
     // exclusive scan of the local histogram (<= 1024 bins; BPT bins per thread)
+    uint32_t staged = 0;
     {
         constexpr int BPT = (MAXB + kPartThreads - 1) / kPartThreads;
         uint32_t c[BPT];
@@ -381,8 +397,12 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
         }
         if (lane == 63) scan_tmp[wave] = incl;
         __syncthreads();
-        uint32_t wbase = 0;
-        for (int w = 0; w < wave; ++w) wbase += scan_tmp[w];
+        uint32_t wbase = 0, all = 0;
+        for (int w = 0; w < kPartThreads / 64; ++w) {
+            if (w < wave) wbase += scan_tmp[w];
+            all += scan_tmp[w];
+        }
+        staged = all;  // records of this tile that take part (== count unless a range pass filters)
         uint32_t ex = wbase + incl - v;
 #pragma unroll
         for (int q = 0; q < BPT; ++q) {
@@ -409,9 +429,11 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
 #pragma unroll
     for (int i = 0; i < kPartItems; ++i) {
         const uint32_t pos = (uint32_t)(i * kPartThreads + tid);
-        if (pos < count) {
+        if (pos < staged) {
             const Key<W> key = key_load<W>(&stage[pos]);
-            const uint32_t b = bin_of(prefix_of<W>(key, L.dmode, L.w0bits), L, nb);
+            uint32_t pfx = prefix_of<W>(key, L.dmode, L.w0bits);
+            (void)select_prefix(pfx, L);
+            const uint32_t b = bin_of(pfx, L, nb);
             const uint32_t g = goff[b] + pos;
             key_store<W>(&out[g], key);
             if (HAS_VAL) vout[g] = vstage[pos];
@@ -1034,8 +1056,17 @@ struct MsdRunner {
     }
 
     // returns false if the caller should use the LSD path instead (too much overflow)
-    bool run(const bbk_reads *rd, const void *d_keys, const uint32_t *d_vals, uint64_t n_in, bool with_mask,
-             MsdOutput &out) {
+    // records two partition levels can take in one pass (bins <= 512 x ~768 of 0.7 CAP records)
+    uint64_t pass_limit() const {
+        static const char *e = getenv("BBK_PASS_LIMIT");  // tests force range passes on small inputs
+        if (e) return strtoull(e, nullptr, 10);
+        return (uint64_t)(0.70 * 512 * 0.75 * kMaxBins * bucket_cap() * 0.98);
+    }
+
+    // Returns 1 = done, 0 = declined (caller uses the LSD path), 2 = the reads hold more records than one
+    // pass takes: *need_sel_bits says into how many hash ranges (2^bits) the caller must split (HASH mode).
+    int run(const bbk_reads *rd, const void *d_keys, const uint32_t *d_vals, uint64_t n_in, bool with_mask,
+            MsdOutput &out, int sel_bits = 0, uint32_t sel_val = 0, int *need_sel_bits = nullptr) {
         constexpr uint32_t kPartTileK = PartCfg<W, 0>::TILE, kPartTileR = PartCfg<W, 1>::TILE;
         const bool from_reads = rd != nullptr;
         const bool has_val = with_mask || d_vals != nullptr;
@@ -1061,12 +1092,20 @@ struct MsdRunner {
         if (N == 0) {
             out.keys.alloc(16);
             out.vals.alloc(16);
-            return true;
+            return 1;
         }
         const uint32_t kPartTile1 = from_reads ? kPartTileR : kPartTileK;  // level-1 tile of this call
         BBK_REQUIRE(N < (1ull << 32) - kPartTileK, BBK_ERR_ARG,
                     "batch holds %llu records; a single device batch is limited to 2^32-1 (split the input)",
                     (unsigned long long)N);
+        if (sel_bits == 0 && from_reads && dmode == MSD_HASH && N > pass_limit() && need_sel_bits) {
+            int bits = 1;
+            while ((N >> bits) > pass_limit() && bits < 8) ++bits;
+            *need_sel_bits = bits;
+            return 2;
+        }
+        const uint64_t Ntot = N;        // instance space of the level-1 tiles
+        if (sel_bits) N = (N >> sel_bits) + (N >> (sel_bits + 4)) + 1;  // planning estimate of this range's share
 
         // ---- bin plan: nb1 (power of two) level-1 bins; level-2 bin counts are chosen per segment below
         const double target = kBucketFill * bucket_cap();
@@ -1080,11 +1119,12 @@ struct MsdRunner {
         const bool verbose = getenv("BBK_VERBOSE") != nullptr;
         if (want / nb1 > 0.75 * kMaxBins) {  // would need a third level: leave to the LSD path
             if (verbose) fprintf(stderr, "[bbk] msd declines: N=%llu needs more than two levels\n", (unsigned long long)N);
-            return false;
+            return 0;
         }
-        PartLevel L1{1, b1, nb1, dmode, w0bits, nullptr, nullptr};
+        PartLevel L1{1, b1, nb1, dmode, w0bits, nullptr, nullptr, sel_bits, sel_val};
 
-        const uint32_t ntiles1 = (uint32_t)((N + kPartTile1 - 1) / kPartTile1);
+        // level-1 tiles cover the whole instance space; a range pass keeps its share of every tile
+        const uint32_t ntiles1 = (uint32_t)((Ntot + kPartTile1 - 1) / kPartTile1);
         ReadSrc S{};
         if (from_reads) {
             tile_read.alloc(((size_t)ntiles1 + 2) * sizeof(uint32_t));
@@ -1093,13 +1133,13 @@ struct MsdRunner {
             check_launch("k_tile_reads");
             S = ReadSrc{rd->d_words, rd->d_woff, rd->d_len, koff.as<uint64_t>(), tile_read.as<uint32_t>(), rd->n, (int)k};
         }
-        TileMap M1{nullptr, nullptr, 1, N};
+        TileMap M1{nullptr, nullptr, 1, Ntot};
 
         // ---- level 1: histogram, offsets, scatter
         DevBuf hist1((size_t)nb1 * 4 + 16), cur1((size_t)nb1 * 4 + 16);
         BBK_HIP(hipMemsetAsync(hist1.p, 0, (size_t)nb1 * 4 + 16, ctx->stream));
         const Key<W> *kin = (const Key<W> *)d_keys;
-        if (nb1 > 1) {
+        if (nb1 > 1 || sel_bits) {
             const double hb = from_reads ? (double)rd->n_words * 8 : (double)N * rec;
             if (from_reads) {
                 launch_part<1, false, true>("part_hist1_reads", hb, ntiles1, nullptr, nullptr, S, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
@@ -1123,8 +1163,17 @@ struct MsdRunner {
             sbin[b + 1] = sbin[b] + snb2[b];
         }
         const uint32_t nbuckets = sbin[nb1];
+        if (sel_bits) {
+            N = off1[nb1];  // the records of this hash range
+            out.instances = N;
+        }
         BBK_REQUIRE(off1[nb1] == (uint32_t)N, BBK_ERR_INTERNAL, "level-1 histogram does not add up (%u vs %llu)",
                     off1[nb1], (unsigned long long)N);
+        if (N == 0) {
+            out.keys.alloc(16);
+            out.vals.alloc(16);
+            return 1;
+        }
         BBK_HIP(hipMemcpyAsync(cur1.p, off1.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
 
         DevBuf bufA(N * rec), bufB(N * rec), valA, valB;
@@ -1150,7 +1199,7 @@ struct MsdRunner {
         BBK_HIP(hipMemcpyAsync(seg_off.p, off1.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(seg_nb2.p, snb2.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(seg_bin.p, sbin.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-        PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>()};
+        PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), sel_bits, sel_val};
         const uint32_t ntiles2 = tstart[nb1];
         TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), nb1, N};
         DevBuf hist2((size_t)nbuckets * 4 + 16), boff(((size_t)nbuckets + 1) * 4 + 16);
@@ -1228,7 +1277,7 @@ struct MsdRunner {
                     dmode, (unsigned long long)N, nb1, nbuckets, mx, bucket_cap(), big.size(), (unsigned long long)novf,
                     (unsigned long long)ovf_rec);
         }
-        if (novf > 256 || ovf_rec > N / 4) return false;
+        if (novf > 256 || ovf_rec > N / 4) return 0;
         if (novf) {
             const ReduceOp rop = op == MSD_OP_OR ? REDUCE_OR : (op == MSD_OP_SUM ? REDUCE_SUM : REDUCE_COUNT);
             for (uint32_t b = 0; b < nbuckets; ++b) {
@@ -1281,6 +1330,43 @@ struct MsdRunner {
                            (uint64_t)nbuckets, D, out.bucket_off.as<uint32_t>());
         check_launch("k_scan_to_u32");
         BBK_HIP(hipStreamSynchronize(ctx->stream));
+        return 1;
+    }
+
+    // run() plus the split into hash ranges when the reads hold more records than one pass takes: every
+    // range is deduplicated on its own (disjoint key sets), the distinct records are concatenated.
+    bool run_all(const bbk_reads *rd, const void *d_keys, const uint32_t *d_vals, uint64_t n_in, bool with_mask,
+                 MsdOutput &out) {
+        int bits = 0;
+        const int r = run(rd, d_keys, d_vals, n_in, with_mask, out, 0, 0, &bits);
+        if (r != 2) return r == 1;
+        const size_t rec = (size_t)W * 8;
+        const bool out_vals = op != MSD_OP_NONE;
+        std::vector<MsdOutput> parts((size_t)1 << bits);
+        uint64_t D = 0, inst = 0;
+        for (uint32_t v = 0; v < (1u << bits); ++v) {
+            if (run(rd, nullptr, nullptr, 0, with_mask, parts[v], bits, v, nullptr) != 1) return false;
+            D += parts[v].n;
+            inst += parts[v].instances;
+            parts[v].bucket_off.release();
+        }
+        out.n = D;
+        out.instances = inst;
+        out.keys.alloc(D * rec + 16);
+        if (out_vals) out.vals.alloc(D * 4 + 16);
+        uint64_t o = 0;
+        for (auto &p : parts) {
+            if (p.n) {
+                BBK_HIP(hipMemcpyAsync(out.keys.as<char>() + o * rec, p.keys.p, p.n * rec, hipMemcpyDeviceToDevice,
+                                       ctx->stream));
+                if (out_vals)
+                    BBK_HIP(hipMemcpyAsync(out.vals.as<uint32_t>() + o, p.vals.p, p.n * 4, hipMemcpyDeviceToDevice,
+                                           ctx->stream));
+            }
+            o += p.n;
+        }
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        out.nbuckets = 0;
         return true;
     }
 };
@@ -1290,11 +1376,11 @@ bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_read
     const int W = (int)words_of(k);
     if (W == 1) {
         MsdRunner<1> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
-        return r.run(rd, d_keys, d_vals, n, with_mask, out);
+        return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
     if (W == 2) {
         MsdRunner<2> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
-        return r.run(rd, d_keys, d_vals, n, with_mask, out);
+        return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
     return false;  // wider keys stay on the LSD path for now
 }
