@@ -466,6 +466,7 @@ struct BucketArgs {
     uint32_t *dcount;            // distinct per bucket; 0xFFFFFFFF = overflow (left untouched)
     const uint32_t *bucket_ids;  // null: bucket = blockIdx.x; else the list of buckets to process
     int k;
+    uint32_t *dbg;               // optional counters (BBK_VERBOSE): [0] buckets that took the all-words fallback
 };
 
 // OP: 0 unique only, 1 COUNT (run length), 2 SUM of vals, 3 OR of vals.  NT threads, CAP = NT * ITEMS.
@@ -504,14 +505,16 @@ __global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_
     }
     __syncthreads();
 
-    // ---- LSD radix sort.  8-byte keys: only the bits in which the bucket's keys differ are sorted
-    // (keys of a KEYS/REF-mode bucket share their top ~16 bits): subtract the bucket minimum, sort
-    // the bits of (max - min).  Wider keys: all populated bits, last word first.
+    // ---- LSD radix sort inside LDS.  Only word 0 is radix-sorted, and only over the bits in which the
+    // bucket's keys differ (keys of a KEYS-mode bucket share their top ~16 bits): subtract the bucket
+    // minimum, sort the bits of (max - min).  Wider keys then order the (short) runs of equal word 0 by
+    // their remaining words with an insertion sort; a bucket with a long run (> 48 keys sharing 32
+    // bases) falls back to radix passes over every word.
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int lastbits = 2 * A.k - 64 * (W - 1);
     uint64_t kmin = 0;
-    int sortbits = lastbits;
-    if (W == 1) {
+    int sortbits = (W == 1) ? lastbits : 64;
+    {
         uint64_t mn = ~0ull, mx = 0;
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -544,9 +547,9 @@ __global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_
         kmin = mn;
         sortbits = 64 - __builtin_clzll((mx - mn) | 1ull);
     }
-    for (int w = W - 1; w >= 0; --w) {
-        const int wbits = (W == 1) ? sortbits : ((w == W - 1) ? lastbits : 64);
-        for (int shift = 0; shift < wbits; shift += 8) {
+    // stable radix passes over bits [0, nbits) of (word `wsel` - base)
+    auto radix_passes = [&](int wsel, uint64_t base, int nbits) {
+        for (int shift = 0; shift < nbits; shift += 8) {
             Key<W> keys[ITEMS];
             uint32_t v[ITEMS];
             uint32_t dr[ITEMS];  // digit << 16 | rank-in-wave
@@ -566,9 +569,9 @@ __global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_
                 if (valid) {
                     keys[i] = key_load<W>(&skeys[p]);
                     if (IN_VAL) v[i] = svals[p];
-                    const uint64_t word = (W == 1) ? keys[i].w[0] - kmin
-                                                   : reinterpret_cast<const uint64_t *>(&skeys[p])[w];
-                    d = (uint32_t)(word >> shift) & 0xFFu;
+                    const uint64_t word = (W == 1) ? keys[i].w[0]
+                                                   : reinterpret_cast<const uint64_t *>(&skeys[p])[wsel];
+                    d = (uint32_t)((word - base) >> shift) & 0xFFu;
                 }
                 const uint64_t peers = match8(d, valid);
                 const uint32_t pre = wave_cnt[wave][d];
@@ -612,6 +615,41 @@ __global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_
                 }
             }
             __syncthreads();
+        }
+    };
+    radix_passes(0, kmin, sortbits);
+    if (W >= 2) {
+        // runs of equal word 0: the thread that owns a run's first record orders the run by words 1..W-1
+        bool bad = false;
+        const uint32_t q0 = (uint32_t)tid * ITEMS;
+        for (uint32_t p = q0; p < q0 + ITEMS && p < n; ++p) {
+            const uint64_t w0 = skeys[p].w[0];
+            if (p > 0 && skeys[p - 1].w[0] == w0) continue;  // not a run start
+            uint32_t e = p + 1;
+            while (e < n && skeys[e].w[0] == w0) ++e;
+            if (e - p <= 1) continue;
+            if (e - p > 48) {
+                bad = true;
+                continue;
+            }
+            for (uint32_t x = p + 1; x < e; ++x) {
+                const Key<W> kx = key_load<W>(&skeys[x]);
+                const uint32_t vx = IN_VAL ? svals[x] : 0u;
+                uint32_t y = x;
+                while (y > p) {
+                    const Key<W> ky = key_load<W>(&skeys[y - 1]);
+                    if (!key_less_words<W>(kx, ky)) break;
+                    key_store<W>(&skeys[y], ky);
+                    if (IN_VAL) svals[y] = svals[y - 1];
+                    --y;
+                }
+                key_store<W>(&skeys[y], kx);
+                if (IN_VAL) svals[y] = vx;
+            }
+        }
+        if (__syncthreads_or(bad)) {
+            if (A.dbg && tid == 0) atomicAdd(&A.dbg[0], 1u);
+            for (int w = W - 1; w >= 0; --w) radix_passes(w, 0ull, (w == W - 1) ? lastbits : 64);
         }
     }
 
@@ -710,7 +748,7 @@ static size_t bucket_smem() {
 // ~30 instructions per record instead of 6 radix passes.  The distinct keys (+ reduced payload)
 // are written back in place in table order.
 constexpr int kHashThreads = 512;
-constexpr int kHashItems = 12;                      // 512 x 12 = 6144 = kBucketCap
+constexpr int kHashItems = 12;                      // 512 x 12 = 6144 records
 constexpr uint32_t kHashSlots = 8192;               // load factor <= 0.75 even if every record is distinct
 
 template <int OP>
@@ -943,9 +981,21 @@ __global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, uint64_t n, 
 // ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------
-constexpr int kBucketItems = 24;                            // CAP = 6144 records (256 threads)
-constexpr uint32_t kBucketCap = kBktThreads * kBucketItems;
-constexpr uint32_t kBucketCapBig = 2 * kBucketCap;          // second chance with 512 threads: 12288 records
+// ODD on purpose: in the blocked phases thread t reads records t*ITEMS + i, i.e. lanes are ITEMS*W*2
+// dwords apart; with an even ITEMS that stride is a multiple of 16 dwords and a wave hits 2-4 LDS banks
+// (16- to 32-way conflicts); with an odd ITEMS the ds_read_b64/b128 of a lane group are conflict-free.
+// 8-byte keys: 256 threads x 23 records (CAP 5888; two workgroups per CU), second chance 512 x 23.
+// Wider keys: the staged bucket takes most of the LDS (one workgroup per CU), so the same ~5.6 k records
+// are spread over 512 threads x 11 to keep 8 waves on the CU.
+template <int W>
+struct BktCfg {
+    static constexpr int NT = (W == 1) ? 256 : 512;
+    static constexpr int ITEMS = (W == 1) ? 23 : 11;
+    static constexpr uint32_t CAP = NT * ITEMS;
+    static constexpr int NT2 = 512;                               // second-chance kernel
+    static constexpr int ITEMS2 = (W == 1) ? 23 : 11;
+    static constexpr uint32_t CAP2 = NT2 * ITEMS2;
+};
 // mean bucket = 0.70 CAP: a bucket holds ~100 distinct genomic k-mers x their multiplicity (~40 at 50x
 // coverage), so its size varies far more than Poisson on the record count would suggest
 constexpr double kBucketFill = 0.70;
@@ -982,8 +1032,9 @@ struct MsdRunner {
     template <int NT, int OP>
     void launch_bucket(uint32_t nblocks, Key<W> *buf, uint32_t *vals, BucketArgs A, double bytes) {
         if (nblocks == 0) return;
-        const size_t sm = bucket_smem<W, NT, kBucketItems, OP>();
-        auto fn = k_bucket<W, NT, kBucketItems, OP>;
+        constexpr int IT = (NT == BktCfg<W>::NT) ? BktCfg<W>::ITEMS : BktCfg<W>::ITEMS2;
+        const size_t sm = bucket_smem<W, NT, IT, OP>();
+        auto fn = k_bucket<W, NT, IT, OP>;
         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)sm));
         KernelTimer t(ctx, "lds_sort", bytes);
@@ -1009,7 +1060,7 @@ struct MsdRunner {
     bool use_hash_dedup() const { return W == 1 && dmode == MSD_HASH && 2 * k < 64; }
     bool use_hashidx_dedup() const { return W >= 2 && dmode == MSD_HASH; }
     // records a first-pass bucket kernel can hold
-    uint32_t bucket_cap() const { return use_hashidx_dedup() ? kHashIdxCap : kBucketCap; }
+    uint32_t bucket_cap() const { return use_hashidx_dedup() ? kHashIdxCap : BktCfg<W>::CAP; }
 
     template <int OP>
     void launch_bucket_hashidx(uint32_t nblocks, Key<W> *buf, uint32_t *vals, BucketArgs A, double bytes) {
@@ -1028,7 +1079,7 @@ struct MsdRunner {
     template <int NT>
     void bucket_dispatch(uint32_t nblocks, Key<W> *buf, uint32_t *vals, BucketArgs A, double bytes,
                          bool allow_hash = true) {
-        if (allow_hash && NT == kBktThreads && use_hashidx_dedup()) {
+        if (allow_hash && use_hashidx_dedup()) {
             switch (op) {
                 case MSD_OP_NONE: launch_bucket_hashidx<0>(nblocks, buf, vals, A, bytes); return;
                 case MSD_OP_COUNT: launch_bucket_hashidx<1>(nblocks, buf, vals, A, bytes); return;
@@ -1037,7 +1088,7 @@ struct MsdRunner {
                 default: BBK_REQUIRE(false, BBK_ERR_ARG, "bad reduce op");
             }
         }
-        if (allow_hash && NT == kBktThreads && use_hash_dedup()) {
+        if (allow_hash && use_hash_dedup()) {
             switch (op) {
                 case MSD_OP_NONE: launch_bucket_hash<0>(nblocks, buf, vals, A, bytes); return;
                 case MSD_OP_COUNT: launch_bucket_hash<1>(nblocks, buf, vals, A, bytes); return;
@@ -1229,9 +1280,11 @@ struct MsdRunner {
 
         // ---- buckets in LDS
         DevBuf dcount((size_t)nbuckets * 4 + 16);
-        BucketArgs A{boff.as<uint32_t>(), dcount.as<uint32_t>(), nullptr, (int)k};
+        DevBuf dbg(64);
+        BBK_HIP(hipMemsetAsync(dbg.p, 0, 64, ctx->stream));
+        BucketArgs A{boff.as<uint32_t>(), dcount.as<uint32_t>(), nullptr, (int)k, verbose ? dbg.as<uint32_t>() : nullptr};
         const double bb = (double)N * (rec + (has_val ? 4 : 0));
-        bucket_dispatch<kBktThreads>(nbuckets, bufB.as<Key<W>>(), valB.as<uint32_t>(), A, bb);
+        bucket_dispatch<BktCfg<W>::NT>(nbuckets, bufB.as<Key<W>>(), valB.as<uint32_t>(), A, bb);
 
         // ---- buckets above CAP: a second pass with 512-thread workgroups (2 x CAP); what still does not
         // fit (a k-mer repeated > 12 k times in one bucket) is finished by the LSD path, one by one
@@ -1243,9 +1296,8 @@ struct MsdRunner {
         uint64_t big_rec = 0;
         // second chance: 8-byte keys -> the 512-thread sorting kernel (2 x 6144 records); wider keys whose
         // first pass was the 4096-record hash kernel -> the 256-thread sorting kernel (6144 records)
-        const uint32_t cap2 = (W == 1) ? kBucketCapBig
-                                       : ((use_hashidx_dedup() && bucket_smem<W, kBktThreads, kBucketItems, 3>() <= 160 * 1024)
-                                              ? kBucketCap : 0u);
+        // (8-byte keys: 2 x CAP; wider keys only gain over the 4096-record hash kernel)
+        const uint32_t cap2 = (W == 1 || use_hashidx_dedup()) ? BktCfg<W>::CAP2 : 0u;
         for (uint32_t b = 0; b < nbuckets; ++b)
             if (hd[b] == 0xFFFFFFFFu && hb[b + 1] - hb[b] <= cap2) {
                 big.push_back(b);
@@ -1254,13 +1306,10 @@ struct MsdRunner {
         if (!big.empty()) {
             DevBuf ids(big.size() * 4);
             BBK_HIP(hipMemcpyAsync(ids.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            BucketArgs A2{boff.as<uint32_t>(), dcount.as<uint32_t>(), ids.as<uint32_t>(), (int)k};
+            BucketArgs A2{boff.as<uint32_t>(), dcount.as<uint32_t>(), ids.as<uint32_t>(), (int)k, nullptr};
             const double b2 = (double)big_rec * (rec + (has_val ? 4 : 0));
-            if constexpr (W == 1)
-                bucket_dispatch<2 * kBktThreads>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2);
-            else
-                bucket_dispatch<kBktThreads>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2,
-                                             /*allow_hash=*/false);
+            bucket_dispatch<BktCfg<W>::NT2>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2,
+                                            /*allow_hash=*/false);
             BBK_HIP(hipMemcpyAsync(hd.data(), dcount.p, (size_t)nbuckets * 4, hipMemcpyDeviceToHost, ctx->stream));
             BBK_HIP(hipStreamSynchronize(ctx->stream));
         }
@@ -1273,6 +1322,10 @@ struct MsdRunner {
         if (verbose) {
             uint32_t mx = 0;
             for (uint32_t b = 0; b < nbuckets; ++b) mx = std::max(mx, hb[b + 1] - hb[b]);
+            uint32_t hdbg[2] = {0, 0};
+            BBK_HIP(hipMemcpyAsync(hdbg, dbg.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+            fprintf(stderr, "[bbk] msd all-words-fallback buckets=%u\n", hdbg[0]);
             fprintf(stderr, "[bbk] msd mode=%d N=%llu nb1=%u buckets=%u max_bucket=%u cap=%u big=%zu lsd=%llu (%llu rec)\n",
                     dmode, (unsigned long long)N, nb1, nbuckets, mx, bucket_cap(), big.size(), (unsigned long long)novf,
                     (unsigned long long)ovf_rec);

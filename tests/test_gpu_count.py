@@ -204,3 +204,16 @@ def test_unsorted_sets(ctx):
         exp, expc = O.kmercount(reads, k, 16, 2, with_counts=True)
         got, gotc = both.export(B.ORDER_REFERENCE_BUCKETS16, with_counts=True)
         assert np.array_equal(got, exp) and np.array_equal(gotc, expc)
+
+
+def test_wide_keys_shared_first_word(ctx):
+    """16-byte keys whose first 32 bases coincide: the bucket sort orders runs of equal word 0 by the
+    other words; > 48 such keys force its all-words radix fallback."""
+    rng = np.random.default_rng(17)
+    prefix = "".join("ACGT"[i] for i in rng.integers(0, 4, size=32))
+    reads = [prefix + "".join("ACGT"[i] for i in rng.integers(0, 4, size=40)) for _ in range(400)]
+    reads += synth_reads(500, read_len=120, genome_len=3000, seed=18)
+    for k in (33, 41, 55, 63):
+        exp, expc = O.kmercount(reads, k, 16, 2, with_counts=True)
+        got, gotc = gpu_final_kmers(ctx, reads, k, with_counts=True)
+        assert np.array_equal(got, exp) and np.array_equal(gotc, expc), k
