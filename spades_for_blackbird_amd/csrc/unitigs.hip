@@ -36,6 +36,11 @@ struct bbk_unitigs {
     bbk::raw_vector<uint32_t> links;    // 2 per link: (from << 1 | from_plus), (to << 1 | to_plus)
     bool has_cov = false;
     std::vector<uint64_t> kc;       // per unitig: sum of (k+1)-mer multiplicities (KC:i:)
+    // Device-resident result (no perfect loops): the GFA text is formatted on the device and streamed
+    // to the file; the host arrays above are filled lazily, only for the calls that need them.
+    uint64_t total_bases = 0;
+    bool host_valid = true;
+    bbk::DevBuf d_bases, d_uoff, d_links;
 };
 
 namespace bbk {
@@ -338,6 +343,98 @@ static void d2h(bbk_ctx *ctx, void *dst, const void *src, size_t bytes) {
     BBK_HIP(hipStreamSynchronize(ctx->stream));
 }
 
+// fills the host arrays of a device-resident result
+static void ensure_host(bbk_ctx *ctx, const bbk_unitigs *cu) {
+    bbk_unitigs *u = const_cast<bbk_unitigs *>(cu);
+    if (u->host_valid) return;
+    BBK_HIP(hipSetDevice(ctx->device));
+    u->bases.resize(u->total_bases);
+    u->offsets.resize(u->n + 1);
+    u->links.resize(2 * u->n_links);
+    if (u->total_bases) d2h_big(ctx, u->bases.data(), u->d_bases.p, u->total_bases);
+    d2h_big(ctx, u->offsets.data(), u->d_uoff.p, (u->n + 1) * 8);
+    if (u->n_links) d2h_big(ctx, u->links.data(), u->d_links.p, u->n_links * 8);
+    u->host_valid = true;
+}
+
+// ---- GFA text on the device ------------------------------------------------------------------
+__device__ inline uint32_t dev_dec_len(uint64_t v) {
+    uint32_t n = 1;
+    while (v >= 10) {
+        v /= 10;
+        ++n;
+    }
+    return n;
+}
+__device__ inline void dev_put_dec(char *dst, uint64_t v, uint32_t len) {
+    for (uint32_t i = 0; i < len; ++i) {
+        dst[len - 1 - i] = (char)('0' + v % 10);
+        v /= 10;
+    }
+}
+constexpr uint32_t kGfaTail = 15;  // "\tDP:f:0\tKC:i:0\n"
+
+__global__ void k_gfa_s_len(const uint64_t *__restrict__ uoff, uint64_t nu, uint64_t *__restrict__ len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nu) len[i] = 2 + dev_dec_len(3 + 2 * i) + 1 + (uoff[i + 1] - uoff[i]) + kGfaTail;
+}
+
+// one wavefront per segment line: "S\t<3+2i>\t<bases>\tDP:f:0\tKC:i:0\n"
+__global__ __launch_bounds__(256) void k_gfa_s_write(const char *__restrict__ bases, const uint64_t *__restrict__ uoff,
+                                                    const uint64_t *__restrict__ pos, uint64_t nu,
+                                                    char *__restrict__ out) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= nu) return;
+    const int lane = threadIdx.x & 63;
+    char *d = out + pos[i];
+    const uint64_t id = 3 + 2 * i;
+    const uint32_t idl = dev_dec_len(id);
+    if (lane == 0) {
+        d[0] = 'S';
+        d[1] = '\t';
+        dev_put_dec(d + 2, id, idl);
+        d[2 + idl] = '\t';
+    }
+    const uint64_t b0 = uoff[i], len = uoff[i + 1] - b0;
+    char *sq = d + 3 + idl;
+    for (uint64_t j = lane; j < len; j += 64) sq[j] = bases[b0 + j];
+    if (lane < (int)kGfaTail) sq[len + lane] = "\tDP:f:0\tKC:i:0\n"[lane];
+}
+
+__global__ void k_gfa_l_len(const uint32_t *__restrict__ links, uint64_t nl, uint32_t klen, uint64_t *__restrict__ len) {
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < nl)
+        len[l] = 2 + dev_dec_len(3 + 2 * (uint64_t)(links[2 * l] >> 1)) + 3 +
+                 dev_dec_len(3 + 2 * (uint64_t)(links[2 * l + 1] >> 1)) + 3 + klen + 2;
+}
+
+// "L\t<e1>\t<+|->\t<e2>\t<+|->\t<k>M\n"
+__global__ void k_gfa_l_write(const uint32_t *__restrict__ links, const uint64_t *__restrict__ pos, uint64_t nl,
+                              uint32_t k, uint32_t klen, char *__restrict__ out) {
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nl) return;
+    char *d = out + pos[l];
+    const uint32_t a = links[2 * l], b = links[2 * l + 1];
+    const uint64_t ia = 3 + 2 * (uint64_t)(a >> 1), ib = 3 + 2 * (uint64_t)(b >> 1);
+    const uint32_t la = dev_dec_len(ia), lb = dev_dec_len(ib);
+    *d++ = 'L';
+    *d++ = '\t';
+    dev_put_dec(d, ia, la);
+    d += la;
+    *d++ = '\t';
+    *d++ = (a & 1u) ? '+' : '-';
+    *d++ = '\t';
+    dev_put_dec(d, ib, lb);
+    d += lb;
+    *d++ = '\t';
+    *d++ = (b & 1u) ? '+' : '-';
+    *d++ = '\t';
+    dev_put_dec(d, k, klen);
+    d += klen;
+    *d++ = 'M';
+    *d++ = '\n';
+}
+
 static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     const int k = (int)x->k;
     const uint64_t n = x->n;
@@ -346,6 +443,7 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     BBK_REQUIRE(n < (1ull << 32) - 2, BBK_ERR_ARG, "extension index too large for one device batch");
     U.offsets.assign(1, 0);
     if (n == 0) return;
+    U.host_valid = true;
 
     // ---- start edges
     DevBuf cnt((n + 1) * 8);
@@ -389,17 +487,13 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     d2h(ctx, &herr, err.p, 4);
     BBK_REQUIRE(herr == 0, BBK_ERR_INTERNAL, "unitig walk (pass 1) failed (code %u)", herr);
 
-    U.bases.resize(NB);
-    U.offsets.resize(NU + 1);
-    if (NB) d2h_big(ctx, U.bases.data(), bases.p, NB);
-    if (NU) d2h_big(ctx, U.offsets.data(), uoff.p, NU * 8);
-    U.offsets[NU] = NB;
+    U.total_bases = NB;
+    BBK_HIP(hipMemcpyAsync(uoff.as<uint64_t>() + NU, &NB, 8, hipMemcpyHostToDevice, ctx->stream));
     starts.release();
     keep.release();
     ulen.release();
     uid.release();
     boff.release();
-    bases.release();
 
     // ---- loop candidates first: without perfect loops (the common case) links are made on the device
     DevBuf flag((n + 1) * 8);
@@ -407,6 +501,13 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
                        x->masks.as<uint8_t>(), visited.as<uint8_t>(), n, flag.as<uint64_t>());
     check_launch("k_loop_candidates");
     const uint64_t NC = exclusive_scan_u64(ctx, flag.as<uint64_t>(), flag.as<uint64_t>(), n);
+    if (NC != 0) {  // perfect loops are appended on the host: bring the paths over now
+        U.bases.resize(NB);
+        U.offsets.resize(NU + 1);
+        if (NB) d2h_big(ctx, U.bases.data(), bases.p, NB);
+        d2h_big(ctx, U.offsets.data(), uoff.p, (NU + 1) * 8);
+        U.host_valid = true;
+    }
 
     // ---- link records: sort by (key, edge) on the device
     std::vector<LinkRec> recs;
@@ -439,12 +540,15 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
             check_launch("k_links<write>");
             unsigned long long hv = 0;
             d2h(ctx, &hv, nv.p, 8);
-            U.links.resize(2 * NL);
-            if (NL) d2h_big(ctx, U.links.data(), dl.p, NL * 8);
             U.n = NU;
             U.n_loops = 0;
             U.n_vertices = hv;
             U.n_links = NL;
+            // the result stays on the device; host copies are made on demand (ensure_host)
+            U.host_valid = false;
+            U.d_bases = std::move(bases);
+            U.d_uoff = std::move(uoff);
+            U.d_links = std::move(dl);
             return;
         }
         raw_vector<uint64_t> hk(2 * NU);
@@ -459,6 +563,8 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     }
     rec.release();
     uoff.release();
+    bases.release();
+    U.total_bases = 0;  // host arrays are authoritative from here on (loops get appended)
 
     // ---- perfect loops: leftover non-junction k-mers (CollectLoops :308-344), walked on the host
     uint64_t n_paths = NU, n_loops = 0;
@@ -567,6 +673,7 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     }
     U.n = n_paths + n_loops;
     U.n_loops = n_loops;
+    U.host_valid = true;
 
     // ---- vertices + links (gfa_writer.cpp:43-52 over construction_helper.hpp:80-90)
     std::vector<uint8_t> selfconj(U.n, 0);
@@ -658,6 +765,7 @@ int bbk_unitigs_add_coverage(bbk_ctx *ctx, bbk_unitigs *u, const bbk_reads *read
     return guarded([&] {
         BBK_REQUIRE(ctx && u && reads, BBK_ERR_ARG, "bbk_unitigs_add_coverage: NULL argument");
         BBK_HIP(hipSetDevice(ctx->device));
+        ensure_host(ctx, u);
         const unsigned k1 = u->k + 1;
         // multiplicities of the canonical (k+1)-mers over reads + rc(reads)
         // (CoverageHashMapBuilder::FillCoverageFromStream, utils/ph_map/coverage_hash_map_builder.hpp:15-38)
@@ -707,13 +815,16 @@ int bbk_unitigs_build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs **out) {
 
 uint64_t bbk_unitigs_count(const bbk_unitigs *u) { return u ? u->n : 0; }
 uint64_t bbk_unitigs_loops(const bbk_unitigs *u) { return u ? u->n_loops : 0; }
-uint64_t bbk_unitigs_total_bases(const bbk_unitigs *u) { return u ? u->bases.size() : 0; }
+uint64_t bbk_unitigs_total_bases(const bbk_unitigs *u) {
+    return u ? (u->host_valid ? u->bases.size() : u->total_bases) : 0;
+}
 uint64_t bbk_unitigs_vertices(const bbk_unitigs *u) { return u ? u->n_vertices : 0; }
 uint64_t bbk_unitigs_links(const bbk_unitigs *u) { return u ? u->n_links : 0; }
 
 int bbk_unitigs_export(bbk_ctx *ctx, const bbk_unitigs *u, char *h_bases, uint64_t *h_offsets) {
     return guarded([&] {
         BBK_REQUIRE(ctx && u, BBK_ERR_ARG, "bbk_unitigs_export: NULL argument");
+        ensure_host(ctx, u);
         if (h_bases && !u->bases.empty()) memcpy(h_bases, u->bases.data(), u->bases.size());
         if (h_offsets) memcpy(h_offsets, u->offsets.data(), u->offsets.size() * sizeof(uint64_t));
     });
@@ -721,7 +832,8 @@ int bbk_unitigs_export(bbk_ctx *ctx, const bbk_unitigs *u, char *h_bases, uint64
 
 int bbk_unitigs_export_links(bbk_ctx *ctx, const bbk_unitigs *u, uint32_t *h_links) {
     return guarded([&] {
-        BBK_REQUIRE(ctx && u && (u->links.empty() || h_links), BBK_ERR_ARG, "bbk_unitigs_export_links: NULL argument");
+        BBK_REQUIRE(ctx && u && (u->n_links == 0 || h_links), BBK_ERR_ARG, "bbk_unitigs_export_links: NULL argument");
+        ensure_host(ctx, u);
         for (uint64_t l = 0; l < u->n_links; ++l) {
             h_links[4 * l] = u->links[2 * l] >> 1;
             h_links[4 * l + 1] = u->links[2 * l] & 1u;
@@ -740,6 +852,92 @@ static size_t fmt_u64(char *dst, uint64_t v) {
     } while (v);
     for (size_t i = 0; i < n; ++i) dst[i] = tmp[n - 1 - i];
     return n;
+}
+
+// GFA text formatted on the device from the device-resident result, then streamed to the file in
+// pinned chunks (copy of chunk i+1 overlaps the pwrite of chunk i).
+static void write_gfa_device(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) {
+    BBK_HIP(hipSetDevice(ctx->device));
+    const uint64_t nu = u->n, nl = u->n_links;
+    DevBuf spos((nu + 1) * 8), lpos((nl + 1) * 8);
+    uint64_t sbytes = 0, lbytes = 0;
+    if (nu) {
+        hipLaunchKernelGGL(k_gfa_s_len, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, ctx->stream,
+                           u->d_uoff.as<uint64_t>(), nu, spos.as<uint64_t>());
+        check_launch("k_gfa_s_len");
+        sbytes = exclusive_scan_u64(ctx, spos.as<uint64_t>(), spos.as<uint64_t>(), nu);
+    }
+    uint32_t klen = 1;
+    for (unsigned v = u->k; v >= 10; v /= 10) ++klen;
+    if (nl) {
+        hipLaunchKernelGGL(k_gfa_l_len, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream,
+                           u->d_links.as<uint32_t>(), nl, klen, lpos.as<uint64_t>());
+        check_launch("k_gfa_l_len");
+        lbytes = exclusive_scan_u64(ctx, lpos.as<uint64_t>(), lpos.as<uint64_t>(), nl);
+    }
+    const uint64_t total = sbytes + lbytes;
+    DevBuf text(total + 16);
+    {
+        KernelTimer t(ctx, "gfa_text", (double)total + (double)u->total_bases);
+        if (nu) {
+            hipLaunchKernelGGL(k_gfa_s_write, dim3((unsigned)((nu * 64 + 255) / 256)), dim3(256), 0, ctx->stream,
+                               u->d_bases.as<char>(), u->d_uoff.as<uint64_t>(), spos.as<uint64_t>(), nu,
+                               text.as<char>());
+            check_launch("k_gfa_s_write");
+        }
+        if (nl) {
+            hipLaunchKernelGGL(k_gfa_l_write, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream,
+                               u->d_links.as<uint32_t>(), lpos.as<uint64_t>(), nl, (uint32_t)u->k, klen,
+                               text.as<char>() + sbytes);
+            check_launch("k_gfa_l_write");
+        }
+    }
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    BBK_REQUIRE(fd >= 0, BBK_ERR_IO, "cannot open %s for writing", path);
+    constexpr size_t kChunk = 32ull << 20;
+    if (!ctx->pinned[0]) {
+        BBK_HIP(hipHostMalloc(&ctx->pinned[0], kChunk, hipHostMallocDefault));
+        BBK_HIP(hipHostMalloc(&ctx->pinned[1], kChunk, hipHostMallocDefault));
+        ctx->pinned_bytes = kChunk;
+    }
+    hipEvent_t ev[2];
+    BBK_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    BBK_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    const size_t nchunks = (size_t)((total + kChunk - 1) / kChunk);
+    auto issue = [&](size_t c) {
+        const size_t off = c * kChunk, sz = std::min<size_t>(kChunk, total - off);
+        (void)hipMemcpyAsync(ctx->pinned[c & 1], text.as<char>() + off, sz, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipEventRecord(ev[c & 1], ctx->stream);
+    };
+    bool ok = true;
+    if (nchunks) issue(0);
+    for (size_t c = 0; c < nchunks && ok; ++c) {
+        BBK_HIP(hipEventSynchronize(ev[c & 1]));
+        if (c + 1 < nchunks) issue(c + 1);
+        const size_t off = c * kChunk, sz = std::min<size_t>(kChunk, total - off);
+        // several writers per chunk: a single pwrite stream into tmpfs runs at ~1/3 of what the box can do
+        const int T = 4;
+        const size_t part = (sz + T - 1) / T;
+#pragma omp parallel for num_threads(T) schedule(static)
+        for (int t = 0; t < T; ++t) {
+            size_t o = (size_t)t * part;
+            const size_t e = std::min(sz, o + part);
+            while (o < e) {
+                const ssize_t w = pwrite(fd, (const char *)ctx->pinned[c & 1] + o, e - o, (off_t)(off + o));
+                if (w <= 0) {
+#pragma omp atomic write
+                    ok = false;
+                    break;
+                }
+                o += (size_t)w;
+            }
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    const int cl = close(fd);
+    BBK_REQUIRE(ok && cl == 0, BBK_ERR_IO, "short write to %s", path);
 }
 
 static inline size_t dec_len(uint64_t v) {
@@ -781,6 +979,11 @@ static bool pwrite_all(int fd, const char *buf, size_t bytes, off_t base) {
 int bbk_unitigs_write_gfa(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) {
     return guarded([&] {
         BBK_REQUIRE(ctx && u && path, BBK_ERR_ARG, "bbk_unitigs_write_gfa: NULL argument");
+        if (!u->host_valid && !u->has_cov) {
+            write_gfa_device(ctx, u, path);
+            return;
+        }
+        ensure_host(ctx, u);
         // S\t<id>\t<seq>\tDP:f:<cov>\tKC:i:<kc>\n with id = 3 + 2i (graph_core.hpp:228; edge i gets
         // min_id + 2i, debruijn_graph_constructor.hpp:457-458); coverage is 0 without -c.
         const uint64_t n = u->n;
@@ -895,6 +1098,7 @@ int bbk_unitigs_write_gfa(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) 
 int bbk_unitigs_write_fastg(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) {
     return guarded([&] {
         BBK_REQUIRE(ctx && u && path, BBK_ERR_ARG, "bbk_unitigs_write_fastg: NULL argument");
+        ensure_host(ctx, u);
         // FastgWriter::WriteSegmentsAndLinks (common/io/graph/fastg_writer.cpp:20-47): one FASTA record per
         // edge AND per conjugate edge; header = name, ':' + comma-separated names of the edges leaving its end
         // vertex (a std::set, i.e. sorted as strings), ';'.  Names are BasicNamingF
@@ -980,6 +1184,7 @@ int bbk_unitigs_write_fastg(bbk_ctx *ctx, const bbk_unitigs *u, const char *path
 int bbk_unitigs_write_fasta(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) {
     return guarded([&] {
         BBK_REQUIRE(ctx && u && path, BBK_ERR_ARG, "bbk_unitigs_write_fasta: NULL argument");
+        ensure_host(ctx, u);
         // >EDGE_<i+1>_length_<len> + 60-column wrapped sequence (projects/gbuilder/main.cpp:183-192,
         // io/reads/header_naming.hpp:14-20, osequencestream.hpp:22-28)
         FILE *f = fopen(path, "wb");
