@@ -217,3 +217,22 @@ def test_wide_keys_shared_first_word(ctx):
         exp, expc = O.kmercount(reads, k, 16, 2, with_counts=True)
         got, gotc = gpu_final_kmers(ctx, reads, k, with_counts=True)
         assert np.array_equal(got, exp) and np.array_equal(gotc, expc), k
+
+
+def test_abi_error_paths(ctx):
+    """Errors surface as status codes + messages, never as crashes (no exception crosses the C ABI)."""
+    import ctypes as C
+    L = B.load_library()
+    r = ctx.reads_from_ascii(["ACGTACGTACGTACGTACGTACGTA"])
+    h = C.c_void_p()
+    assert L.bbk_count(ctx._h, r._h, 0, B.BOTH_STRANDS, C.byref(h)) == -1      # k out of range
+    assert b"out of range" in L.bbk_last_error()
+    assert L.bbk_count(ctx._h, r._h, 128, B.BOTH_STRANDS, C.byref(h)) == -1
+    assert L.bbk_count(ctx._h, r._h, 21, 0, C.byref(h)) == -1                  # neither strand mode
+    assert L.bbk_count(ctx._h, r._h, 21, B.BOTH_STRANDS | B.CANONICAL, C.byref(h)) == -1
+    assert L.bbk_count(None, r._h, 21, B.BOTH_STRANDS, C.byref(h)) == -1
+    assert L.bbk_extindex_build(ctx._h, r._h, 127, C.byref(h)) == -1           # k+1 must be < 128
+    with pytest.raises(B.BBKError):
+        ctx.count(r, 21, B.BOTH_STRANDS).write_final_kmers("/nonexistent_dir/x/final_kmers")
+    c2 = C.c_void_p()
+    assert L.bbk_ctx_create(9999, C.byref(c2)) == -1

@@ -257,3 +257,20 @@ def test_fastg_structure(ctx, tmp_path):
         assert recs[x][1][-k:] == recs[y][1][:k]
     for x, (succ, _) in recs.items():
         assert succ == sorted(succ)
+
+
+def test_long_reads_and_long_unitigs(ctx, tmp_path):
+    """Contig-sized input records (one partition tile lies inside a single read) and an error-free genome
+    (unitigs of thousands of k-mers walked by single threads)."""
+    rng = np.random.default_rng(23)
+    genome = "".join("ACGT"[i] for i in rng.integers(0, 4, size=60000))
+    reads = [genome[:40000], genome[30000:], rc(genome[10000:35000]), "N" * 10 + genome[5000:5100]]
+    k = 31
+    txt, u = gpu_gfa(ctx, reads, k, tmp_path)
+    ou = O.ExtIndex(reads, k, 1).unitigs()
+    assert (len(u), u.n_loops) == (ou.n, ou.n_loops)
+    assert max(len(s) for s in u.sequences()) > 10000
+    assert gfa_canon.canon_md5(txt, k) == gfa_canon.canon_md5(ou.gfa()[0], k)  # an error-free genome has no links
+    r = ctx.reads_from_ascii(reads)
+    got = ctx.count(r, k, B.BOTH_STRANDS).export(B.ORDER_REFERENCE_BUCKETS16)
+    assert np.array_equal(got, O.kmercount(reads, k, 16, 2))
