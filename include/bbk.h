@@ -74,6 +74,11 @@ int bbk_reads_from_device(bbk_ctx *ctx, const void *d_words, const void *d_word_
  * (seed_genome), uniform start, strand flip p=0.5, substitution rate sub_rate (seed_reads). */
 int bbk_reads_synth(bbk_ctx *ctx, uint64_t n_reads, uint32_t read_len, uint64_t genome_len, double sub_rate,
                     uint64_t seed_genome, uint64_t seed_reads, bbk_reads **out);
+/* SPAdes binary read cache of single reads (<prefix>.seq / <prefix>.off, io::BinaryWriter::ToBinary,
+ * common/io/reads/binary_converter.cpp:50-113; record layout Sequence::BinWrite, common/sequence/sequence.hpp:410-442).
+ * Its 2-bit words are exactly the device layout: records are copied, not re-encoded. */
+int bbk_reads_from_spades_binary(bbk_ctx *ctx, const char *seq_path, bbk_reads **out);
+int bbk_reads_write_spades_binary(bbk_ctx *ctx, const bbk_reads *r, const char *prefix);
 uint64_t bbk_reads_count(const bbk_reads *r);
 uint64_t bbk_reads_bases(const bbk_reads *r);
 /* Copy read i back as ASCII (tests); dst must hold len+1 bytes; returns the length via *len. */

@@ -55,7 +55,6 @@ struct PartCfg {
 };
 constexpr int kMaxBins = 1024;
 constexpr int kBktThreads = 256;
-constexpr int kBktWaves = kBktThreads / 64;
 
 // 32-bit partition prefix: bucket order == prefix order (only ~20 top bits are ever consumed)
 template <int W>
@@ -265,7 +264,13 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
     bool have = false;
     const uint64_t *rw = nullptr;
     uint32_t Lr = 0, rstart = 0;
-    uint64_t fwd = 0, Rv = 0, wcur = 0;
+    uint64_t wcur = 0;
+    RollState<W> roll;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        roll.fwd.w[w] = 0;
+        roll.r[w] = 0;
+    }
     if (SRC == 1 && cached) {
         const uint32_t first = (uint32_t)tid * kPartItems;
         if (first < count) rl = read_of(s_rel, nr, jbase + first);
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
                     }
                     vals[i] = m;
                 }
-            } else if constexpr (W == 1) {
+            } else {
                 const uint32_t jr = jbase + local;
                 if (jr >= nxt) {  // crossed into a later read
                     while (rl + 1 < nr && s_rel[rl + 1] <= jr) ++rl;
@@ -321,28 +326,21 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
                     have = false;
                 }
                 const uint32_t p = jr - rstart;
-                const uint32_t k_ = (uint32_t)S.k, pad = 64u - 2u * k_;
+                const uint32_t k_ = (uint32_t)S.k;
                 if (!have) {
                     const uint64_t r = (uint64_t)r0 + rl;
                     rw = S.words + S.woff[r];
                     Lr = S.len[r];
-                    const uint32_t wi = p >> 5, sh = (p & 31u) << 1, lastw = (Lr - 1u) >> 5;
-                    const uint64_t lo = rw[wi];
-                    const uint64_t hi = rw[wi + 1 <= lastw ? wi + 1 : lastw];
-                    fwd = (lo >> sh) | ((hi << 1) << (63u - sh));
-                    fwd = (fwd << pad) >> pad;
-                    Rv = rev2(fwd);
+                    roll_init<W>(roll, kmer_extract<W>(rw, p, S.k));
                     wcur = rw[(p + k_ - 1u) >> 5];
                     have = true;
                 } else {
                     const uint32_t q = p + k_ - 1u;  // the base that enters
                     if ((q & 31u) == 0) wcur = rw[q >> 5];
-                    const uint64_t b = (wcur >> ((q & 31u) << 1)) & 3ull;
-                    fwd = (fwd >> 2) | (b << (2u * (k_ - 1u)));
-                    Rv = (Rv << 2) | (b << pad);
+                    roll_step<W>(roll, S.k, (uint32_t)((wcur >> ((q & 31u) << 1)) & 3ull));
                 }
-                const bool minimal = Rv <= ((~fwd) << pad);
-                keys[i].w[0] = minimal ? fwd : ((~Rv) >> pad);
+                bool minimal;
+                keys[i] = roll_canonical<W>(roll, S.k, &minimal);
                 if (HAS_VAL) {
                     uint32_t m = 0;
                     if (p + k_ < Lr) {
@@ -355,8 +353,6 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
                     }
                     vals[i] = m;
                 }
-            } else {
-                read_record<W, HAS_VAL>(S, jbase + local, s_rel, r0, nr, rl, keys[i], vals[i]);
             }
             uint32_t pfx = prefix_of<W>(keys[i], L.dmode, L.w0bits);
             if (select_prefix(pfx, L)) {

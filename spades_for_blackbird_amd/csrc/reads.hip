@@ -5,8 +5,10 @@
 // read generator of SURVEY.md 8(d) used by bench.py.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "bbk_internal.h"
@@ -167,6 +169,108 @@ int bbk_reads_from_ascii(bbk_ctx *ctx, const char *h_bases, const uint64_t *h_of
         rd->d_woff = rd->own_woff.as<uint64_t>();
         rd->d_len = rd->own_len.as<uint32_t>();
         *out = guard.release();
+    });
+}
+
+// ---- SPAdes binary read cache (.seq / .off), single reads ---------------------------------------
+// Format written by io::BinaryWriter::ToBinary (common/io/reads/binary_converter.cpp:50-113):
+//   .seq : ReadStreamStat {u64 read_count, u64 max_len, u64 total_len} (io/reads/read_stream.hpp:19-36), then
+//          per read: u64 size, ceil(size/32) u64 words of 2-bit bases (Sequence::BinWrite,
+//          common/sequence/sequence.hpp:410-442 -- the same LSB-first layout as the device arrays, so a
+//          record is copied, not re-encoded), u16 left_offset, u16 right_offset (SingleReadSeq::BinWrite,
+//          io/reads/single_read.hpp:286-299);
+//   .off : the byte offset in .seq of every 100th read, starting with read 0 (CHUNK = 100,
+//          binary_converter.hpp:35, binary_converter.cpp:70-78).
+int bbk_reads_from_spades_binary(bbk_ctx *ctx, const char *seq_path, bbk_reads **out) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx && seq_path && out, BBK_ERR_ARG, "bbk_reads_from_spades_binary: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        FILE *f = fopen(seq_path, "rb");
+        BBK_REQUIRE(f != nullptr, BBK_ERR_IO, "cannot open %s", seq_path);
+        std::unique_ptr<FILE, int (*)(FILE *)> fg(f, fclose);
+        uint64_t hdr[3];
+        BBK_REQUIRE(fread(hdr, 8, 3, f) == 3, BBK_ERR_IO, "%s: truncated header", seq_path);
+        const uint64_t n_reads = hdr[0];
+        std::vector<uint64_t> woff(n_reads + 1), words;
+        std::vector<uint32_t> len(n_reads);
+        words.reserve(hdr[2] / 32 + n_reads + 1);
+        uint64_t bases = 0;
+        for (uint64_t r = 0; r < n_reads; ++r) {
+            uint64_t size;
+            BBK_REQUIRE(fread(&size, 8, 1, f) == 1, BBK_ERR_IO, "%s: truncated at read %llu", seq_path,
+                        (unsigned long long)r);
+            BBK_REQUIRE(size < (1ull << 32), BBK_ERR_IO, "%s: read %llu has an implausible size", seq_path,
+                        (unsigned long long)r);
+            const uint64_t nw = (size + 31) / 32;
+            woff[r] = words.size();
+            words.resize(words.size() + nw);
+            BBK_REQUIRE(nw == 0 || fread(words.data() + woff[r], 8, nw, f) == nw, BBK_ERR_IO,
+                        "%s: truncated at read %llu", seq_path, (unsigned long long)r);
+            // bits above the last base are not guaranteed to be zero in the cache: clear them
+            if (size & 31) words[woff[r] + nw - 1] &= (1ull << ((size & 31) * 2)) - 1;
+            uint16_t offs[2];
+            BBK_REQUIRE(fread(offs, 2, 2, f) == 2, BBK_ERR_IO, "%s: truncated at read %llu", seq_path,
+                        (unsigned long long)r);
+            len[r] = (uint32_t)size;
+            bases += size;
+        }
+        woff[n_reads] = words.size();
+        words.push_back(0);
+        auto rd = new bbk_reads();
+        std::unique_ptr<bbk_reads> guard(rd);
+        rd->ctx = ctx;
+        rd->n = n_reads;
+        rd->n_words = words.size() - 1;
+        rd->bases = bases;
+        rd->own_words.alloc(words.size() * sizeof(uint64_t));
+        rd->own_woff.alloc((n_reads + 1) * sizeof(uint64_t));
+        rd->own_len.alloc((n_reads + 1) * sizeof(uint32_t));
+        BBK_HIP(hipMemcpyAsync(rd->own_words.p, words.data(), words.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(rd->own_woff.p, woff.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (n_reads)
+            BBK_HIP(hipMemcpyAsync(rd->own_len.p, len.data(), n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        rd->d_words = rd->own_words.as<uint64_t>();
+        rd->d_woff = rd->own_woff.as<uint64_t>();
+        rd->d_len = rd->own_len.as<uint32_t>();
+        *out = guard.release();
+    });
+}
+
+int bbk_reads_write_spades_binary(bbk_ctx *ctx, const bbk_reads *r, const char *prefix) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx && r && prefix, BBK_ERR_ARG, "bbk_reads_write_spades_binary: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        std::vector<uint64_t> woff(r->n + 1), words(r->n_words + 1);
+        std::vector<uint32_t> len(r->n + 1);
+        BBK_HIP(hipMemcpyAsync(woff.data(), r->d_woff, (r->n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (r->n) BBK_HIP(hipMemcpyAsync(len.data(), r->d_len, r->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (r->n_words)
+            BBK_HIP(hipMemcpyAsync(words.data(), r->d_words, r->n_words * 8, hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        const std::string sp = std::string(prefix) + ".seq", op = std::string(prefix) + ".off";
+        FILE *fs = fopen(sp.c_str(), "wb");
+        BBK_REQUIRE(fs != nullptr, BBK_ERR_IO, "cannot open %s for writing", sp.c_str());
+        std::unique_ptr<FILE, int (*)(FILE *)> gs(fs, fclose);
+        FILE *fo = fopen(op.c_str(), "wb");
+        BBK_REQUIRE(fo != nullptr, BBK_ERR_IO, "cannot open %s for writing", op.c_str());
+        std::unique_ptr<FILE, int (*)(FILE *)> go(fo, fclose);
+        uint64_t hdr[3] = {r->n, 0, 0};
+        for (uint64_t i = 0; i < r->n; ++i) {
+            hdr[1] = std::max<uint64_t>(hdr[1], len[i]);
+            hdr[2] += len[i];
+        }
+        bool ok = fwrite(hdr, 8, 3, fs) == 3;
+        uint64_t pos = 24;
+        const uint16_t zero[2] = {0, 0};
+        for (uint64_t i = 0; i < r->n && ok; ++i) {
+            if (i % 100 == 0) ok = fwrite(&pos, 8, 1, fo) == 1;
+            const uint64_t size = len[i], nw = (size + 31) / 32;
+            ok = ok && fwrite(&size, 8, 1, fs) == 1 && (nw == 0 || fwrite(words.data() + woff[i], 8, nw, fs) == nw) &&
+                 fwrite(zero, 2, 2, fs) == 2;
+            pos += 8 + nw * 8 + 4;
+        }
+        BBK_REQUIRE(ok, BBK_ERR_IO, "short write to %s", sp.c_str());
     });
 }
 

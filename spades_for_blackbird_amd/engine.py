@@ -14,7 +14,8 @@ ORDER_SORTED, ORDER_REFERENCE_BUCKETS16 = 0, 1
 SYMBOLS = [
     "bbk_last_error", "bbk_version", "bbk_ctx_create", "bbk_ctx_destroy", "bbk_ctx_set_stream",
     "bbk_ctx_synchronize", "bbk_ctx_profile_enable", "bbk_ctx_profile_reset", "bbk_ctx_profile_get",
-    "bbk_reads_from_ascii", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_count", "bbk_reads_bases",
+    "bbk_reads_from_ascii", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_from_spades_binary",
+    "bbk_reads_write_spades_binary", "bbk_reads_count", "bbk_reads_bases",
     "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
     "bbk_count", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k",
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
@@ -58,6 +59,8 @@ def load_library():
     L.bbk_reads_from_ascii.argtypes = [vp, C.c_char_p, vp, u64, C.POINTER(vp)]
     L.bbk_reads_from_device.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
     L.bbk_reads_synth.argtypes = [vp, u64, u32, u64, C.c_double, u64, u64, C.POINTER(vp)]
+    L.bbk_reads_from_spades_binary.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    L.bbk_reads_write_spades_binary.argtypes = [vp, vp, C.c_char_p]
     L.bbk_reads_count.restype = u64
     L.bbk_reads_count.argtypes = [vp]
     L.bbk_reads_bases.restype = u64
@@ -181,6 +184,12 @@ class Context:
         r._keep = (d_words, d_word_off, d_len)
         return r
 
+    def reads_from_spades_binary(self, seq_path):
+        """SPAdes binary read cache (<prefix>.seq)."""
+        h = C.c_void_p()
+        _check(self._L.bbk_reads_from_spades_binary(self._h, seq_path.encode(), C.byref(h)))
+        return Reads(self, h)
+
     def reads_synth(self, n_reads, read_len=150, genome_len=None, sub_rate=0.005, seed_genome=42, seed_reads=43):
         if genome_len is None:
             genome_len = max(read_len, n_reads * read_len // 50)
@@ -262,6 +271,9 @@ class Reads(_Handle):
         buf = np.zeros(total + 1, dtype=np.uint8)
         _check(self._L.bbk_reads_export_ascii(self.ctx._h, self._h, _ptr(buf), _ptr(offs), total))
         return buf[:total].tobytes(), offs
+
+    def write_spades_binary(self, prefix):
+        _check(self._L.bbk_reads_write_spades_binary(self.ctx._h, self._h, prefix.encode()))
 
     def to_list(self):
         blob, offs = self.to_ascii()

@@ -50,6 +50,15 @@ inline void check(int rc, const char *what) {
 
 // Reads every file into one host batch (names and qualities dropped) and uploads it.
 inline bbk_reads *load_reads(bbk_ctx *ctx, const std::vector<std::string> &files, uint64_t *n_reads) {
+    // a single SPAdes binary read cache (<prefix>.seq) is taken as is
+    if (files.size() == 1 && ends_with(files[0], ".seq")) {
+        info("Processing %s (binary read cache)", files[0].c_str());
+        bbk_reads *r = nullptr;
+        check(bbk_reads_from_spades_binary(ctx, files[0].c_str(), &r), "bbk_reads_from_spades_binary");
+        if (n_reads) *n_reads = bbk_reads_count(r);
+        info("Total %llu reads processed", (unsigned long long)bbk_reads_count(r));
+        return r;
+    }
     ReadBatch batch;
     for (const std::string &f : files) {
         info("Processing %s", f.c_str());

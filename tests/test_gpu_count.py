@@ -236,3 +236,36 @@ def test_abi_error_paths(ctx):
         ctx.count(r, 21, B.BOTH_STRANDS).write_final_kmers("/nonexistent_dir/x/final_kmers")
     c2 = C.c_void_p()
     assert L.bbk_ctx_create(9999, C.byref(c2)) == -1
+
+
+def test_spades_binary_read_cache(ctx, tmp_path):
+    """SPAdes binary read cache (.seq/.off): written from the device arrays and read back; the layout is
+    checked field by field against the reference's writer (binary_converter.cpp:50-113; no cache file ships
+    with the reference, so its bytes are "parity unpinned")."""
+    import struct
+    reads = synth_reads(250, read_len=100, genome_len=3000, seed=41) + ["ACGT", "A" * 33, "ACGTNNNNACGTAC"]
+    r = ctx.reads_from_ascii(reads)
+    prefix = str(tmp_path / "lib")
+    r.write_spades_binary(prefix)
+    data = open(prefix + ".seq", "rb").read()
+    n, max_len, total = struct.unpack_from("<QQQ", data, 0)
+    kept = r.to_list()
+    assert (n, max_len, total) == (len(kept), max(len(x) for x in kept), sum(len(x) for x in kept))
+    pos, offs = 24, []
+    for i, s in enumerate(kept):
+        if i % 100 == 0:
+            offs.append(pos)
+        (size,) = struct.unpack_from("<Q", data, pos)
+        assert size == len(s)
+        nw = (size + 31) // 32
+        words = struct.unpack_from("<%dQ" % nw, data, pos + 8)
+        dec = "".join("ACGT"[(words[j // 32] >> (2 * (j % 32))) & 3] for j in range(size))
+        assert dec == s
+        pos += 8 + 8 * nw + 4
+    assert pos == len(data)
+    assert list(struct.unpack("<%dQ" % len(offs), open(prefix + ".off", "rb").read())) == offs
+    r2 = ctx.reads_from_spades_binary(prefix + ".seq")
+    assert r2.to_list() == kept
+    a = ctx.count(r, 21, B.BOTH_STRANDS).export(B.ORDER_REFERENCE_BUCKETS16)
+    b = ctx.count(r2, 21, B.BOTH_STRANDS).export(B.ORDER_REFERENCE_BUCKETS16)
+    assert np.array_equal(a, b)
