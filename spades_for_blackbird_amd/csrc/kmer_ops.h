@@ -170,62 +170,6 @@ __device__ inline uint32_t kmer_base(const Key<W> &x, int i) {
     return (uint32_t)((x.w[i >> 5] >> ((i & 31) << 1)) & 3ull);
 }
 
-// ---- rolling canonical k-mer of any width --------------------------------------------------------
-// State: fwd (the k-mer) and R = fwd read backwards as a 64W-bit number, left aligned (base 0 in the top
-// pair of word W-1).  One step with entering base b:  fwd = fwd>>2 | b<<2(k-1),  R = R<<2 | b<<pad with
-// pad = 64W - 2k (< 64).  Reverse complement = (~R)>>pad; IsMinimal (rtseq.hpp:407-415) is the
-// comparison R <= (~fwd)<<pad of two 64W-bit numbers.
-template <int W>
-struct RollState {
-    Key<W> fwd;
-    uint64_t r[W];
-};
-
-template <int W>
-__device__ inline void roll_init(RollState<W> &s, const Key<W> &fwd) {
-    s.fwd = fwd;
-#pragma unroll
-    for (int i = 0; i < W; ++i) s.r[i] = rev2(fwd.w[W - 1 - i]);
-}
-
-template <int W>
-__device__ inline void roll_step(RollState<W> &s, int k, uint32_t b) {
-    s.fwd = kmer_shl<W>(s.fwd, k, b);
-    const uint32_t pad = 64u * W - 2u * (uint32_t)k;
-#pragma unroll
-    for (int i = W - 1; i > 0; --i) s.r[i] = (s.r[i] << 2) | (s.r[i - 1] >> 62);
-    s.r[0] = (s.r[0] << 2) | ((uint64_t)b << pad);
-}
-
-template <int W>
-__device__ inline Key<W> roll_canonical(const RollState<W> &s, int k, bool *minimal) {
-    const uint32_t pad = 64u * W - 2u * (uint32_t)k;
-    // C = (~fwd) << pad, compared with R from the most significant word down
-    bool lt = false, decided = false;
-#pragma unroll
-    for (int i = W - 1; i >= 0; --i) {
-        uint64_t c = (~s.fwd.w[i]) << pad;
-        if (pad != 0 && i > 0) c |= (~s.fwd.w[i - 1]) >> (64u - pad);
-        if (!decided && s.r[i] != c) {
-            lt = s.r[i] < c;
-            decided = true;
-        }
-    }
-    *minimal = decided ? lt : true;  // equal: the k-mer is its own reverse complement
-    Key<W> rc;
-#pragma unroll
-    for (int i = 0; i < W; ++i) {
-        uint64_t v = (~s.r[i]) >> pad;
-        if (pad != 0 && i + 1 < W) v |= (~s.r[i + 1]) << (64u - pad);
-        rc.w[i] = v;
-    }
-    // the top word of rc carries ~0 bits shifted in from nowhere only below 2k: mask its padding
-    const int vb = 2 * k - 64 * (W - 1);
-    if (vb < 64) rc.w[W - 1] &= (1ull << vb) - 1ull;
-    return key_select<W>(*minimal, s.fwd, rc);
-}
-
-
 // ---- XXH3-64 (xxHash 0.8.0, seed 0, default secret) for 8/16/24/32-byte inputs -----------------
 // Restated from the published algorithm; the reference calls it through RtSeq::GetHash
 // (rtseq.hpp:681-687) -> KMerSegmentPolicy (utils/kmer_mph/kmer_buckets.hpp:28-33).

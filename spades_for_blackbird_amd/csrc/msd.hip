@@ -264,13 +264,7 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
     bool have = false;
     const uint64_t *rw = nullptr;
     uint32_t Lr = 0, rstart = 0;
-    uint64_t wcur = 0;
-    RollState<W> roll;
-#pragma unroll
-    for (int w = 0; w < W; ++w) {
-        roll.fwd.w[w] = 0;
-        roll.r[w] = 0;
-    }
+    uint64_t fwd = 0, Rv = 0, wcur = 0;
     if (SRC == 1 && cached) {
         const uint32_t first = (uint32_t)tid * kPartItems;
         if (first < count) rl = read_of(s_rel, nr, jbase + first);
@@ -317,7 +311,7 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
                     }
                     vals[i] = m;
                 }
-            } else {
+            } else if constexpr (W == 1) {
                 const uint32_t jr = jbase + local;
                 if (jr >= nxt) {  // crossed into a later read
                     while (rl + 1 < nr && s_rel[rl + 1] <= jr) ++rl;
@@ -326,21 +320,28 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
                     have = false;
                 }
                 const uint32_t p = jr - rstart;
-                const uint32_t k_ = (uint32_t)S.k;
+                const uint32_t k_ = (uint32_t)S.k, pad = 64u - 2u * k_;
                 if (!have) {
                     const uint64_t r = (uint64_t)r0 + rl;
                     rw = S.words + S.woff[r];
                     Lr = S.len[r];
-                    roll_init<W>(roll, kmer_extract<W>(rw, p, S.k));
+                    const uint32_t wi = p >> 5, sh = (p & 31u) << 1, lastw = (Lr - 1u) >> 5;
+                    const uint64_t lo = rw[wi];
+                    const uint64_t hi = rw[wi + 1 <= lastw ? wi + 1 : lastw];
+                    fwd = (lo >> sh) | ((hi << 1) << (63u - sh));
+                    fwd = (fwd << pad) >> pad;
+                    Rv = rev2(fwd);
                     wcur = rw[(p + k_ - 1u) >> 5];
                     have = true;
                 } else {
                     const uint32_t q = p + k_ - 1u;  // the base that enters
                     if ((q & 31u) == 0) wcur = rw[q >> 5];
-                    roll_step<W>(roll, S.k, (uint32_t)((wcur >> ((q & 31u) << 1)) & 3ull));
+                    const uint64_t b = (wcur >> ((q & 31u) << 1)) & 3ull;
+                    fwd = (fwd >> 2) | (b << (2u * (k_ - 1u)));
+                    Rv = (Rv << 2) | (b << pad);
                 }
-                bool minimal;
-                keys[i] = roll_canonical<W>(roll, S.k, &minimal);
+                const bool minimal = Rv <= ((~fwd) << pad);
+                keys[i].w[0] = minimal ? fwd : ((~Rv) >> pad);
                 if (HAS_VAL) {
                     uint32_t m = 0;
                     if (p + k_ < Lr) {
@@ -353,6 +354,8 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
                     }
                     vals[i] = m;
                 }
+            } else {
+                read_record<W, HAS_VAL>(S, jbase + local, s_rel, r0, nr, rl, keys[i], vals[i]);
             }
             uint32_t pfx = prefix_of<W>(keys[i], L.dmode, L.w0bits);
             if (select_prefix(pfx, L)) {
