@@ -418,6 +418,15 @@ uint64_t bbk_kmerset_size(const bbk_kmerset *s) { return s ? s->n : 0; }
 unsigned bbk_kmerset_k(const bbk_kmerset *s) { return s ? s->k : 0; }
 uint64_t bbk_kmerset_instances(const bbk_kmerset *s) { return s ? s->instances : 0; }
 
+static bool is_device_ptr(const void *p) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // plain host memory is not an error
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+}
+
 static void export_ordered(bbk_ctx *ctx, const bbk_kmerset *s, const PassDesc *pd, void *dst_keys, void *dst_counts,
                            uint64_t *h_counts) {
     BBK_HIP(hipSetDevice(ctx->device));
@@ -435,23 +444,22 @@ static void export_ordered(bbk_ctx *ctx, const bbk_kmerset *s, const PassDesc *p
         BBK_HIP(hipStreamSynchronize(ctx->stream));
         return;
     }
-    DevBuf a(s->n * rec), b(s->n * rec), ca, cb;
-    BBK_HIP(hipMemcpyAsync(a.p, s->keys.p, s->n * rec, hipMemcpyDeviceToDevice, ctx->stream));
-    if (wc) {
-        ca.alloc(s->n * 4);
-        cb.alloc(s->n * 4);
-        BBK_HIP(hipMemcpyAsync(ca.p, s->counts.p, s->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    }
     if (h_counts) {
         uint64_t hc[256];
-        digit_histogram(ctx, (int)s->W, a.p, s->n, *pd, hc);
+        digit_histogram(ctx, (int)s->W, s->keys.p, s->n, *pd, hc);
         for (unsigned i = 0; i < pd->nb; ++i) h_counts[i] = hc[i];
     }
-    // one stable pass on the bucket digit keeps the ascending order inside each bucket
-    sort_records(ctx, (int)s->W, a.p, b.p, wc ? ca.as<uint32_t>() : nullptr, wc ? cb.as<uint32_t>() : nullptr, s->n,
-                 std::vector<PassDesc>{*pd});
-    BBK_HIP(hipMemcpyAsync(dst_keys, a.p, s->n * rec, hipMemcpyDefault, ctx->stream));
-    if (wc) BBK_HIP(hipMemcpyAsync(dst_counts, ca.p, s->n * 4, hipMemcpyDefault, ctx->stream));
+    // One stable pass on the bucket digit keeps the ascending order inside each bucket.  It reads the set
+    // and writes straight into the caller's buffer when that is device memory (no staging copies).
+    const bool kdev = is_device_ptr(dst_keys), cdev = !wc || is_device_ptr(dst_counts);
+    DevBuf tk, tc;
+    if (!kdev) tk.alloc(s->n * rec);
+    if (wc && !cdev) tc.alloc(s->n * 4);
+    void *ok = kdev ? dst_keys : tk.p;
+    uint32_t *oc = wc ? (cdev ? (uint32_t *)dst_counts : tc.as<uint32_t>()) : nullptr;
+    partition_records(ctx, (int)s->W, s->keys.p, ok, wc ? s->counts.as<uint32_t>() : nullptr, oc, s->n, *pd);
+    if (!kdev) BBK_HIP(hipMemcpyAsync(dst_keys, tk.p, s->n * rec, hipMemcpyDeviceToHost, ctx->stream));
+    if (wc && !cdev) BBK_HIP(hipMemcpyAsync(dst_counts, tc.p, s->n * 4, hipMemcpyDeviceToHost, ctx->stream));
     BBK_HIP(hipStreamSynchronize(ctx->stream));
 }
 

@@ -37,24 +37,31 @@
 
 namespace bbk {
 
-// Partition tile: 8192 records of 8 B (4096 of 16 B) staged in LDS.  From a key array 512 threads x 16
-// items keep the loads wide; from reads (extraction fused: instruction- and latency-bound) the same
-// tile is spread over 1024 threads x 8 items so that a CU holds 16 waves at one workgroup per CU.
+// Partition tile of a key array: 8192 records of 8 B (4096 of 16 B) staged in LDS, 512 threads x 16
+// (x 8) items so the loads stay wide.  Reads are partitioned by k_part_reads (own geometry below).
 #ifndef BBK_KEYS_TILE
 #define BBK_KEYS_TILE 8192
 #endif
 #ifndef BBK_KEYS_THREADS
 #define BBK_KEYS_THREADS 512
 #endif
-constexpr int part_threads(int src) { return src == 1 ? 1024 : BBK_KEYS_THREADS; }
-template <int W, int SRC>
+template <int W>
 struct PartCfg {
-    static constexpr int TILE = (W == 1) ? (SRC == 1 ? 8192 : BBK_KEYS_TILE) : 4096;
-    static constexpr int THREADS = part_threads(SRC);
+    static constexpr int TILE = (W == 1) ? BBK_KEYS_TILE : 4096;
+    static constexpr int THREADS = BBK_KEYS_THREADS;
     static constexpr int ITEMS = TILE / THREADS;
 };
+// Fused extraction + level-1 partition: a lane owns one CHUNK of up to CH consecutive k-mer positions of
+// ONE read (8-byte keys: 8, rolled base by base; wider keys: 4), a workgroup 1024 chunks.
+constexpr int kRdThreads = 1024;
+constexpr int kRdSlots = 1024;  // reads of one tile whose cursor tables fit LDS
+constexpr int kRdWords = 2048;  // packed read words of one tile staged in LDS (150 bp reads need ~330)
+template <int W>
+struct RdCfg {
+    static constexpr int CH = (W == 1) ? 8 : 4;
+    static constexpr int TILE = kRdThreads * CH;
+};
 constexpr int kMaxBins = 1024;
-constexpr int kBktThreads = 256;
 
 // 32-bit partition prefix: bucket order == prefix order (only ~20 top bits are ever consumed)
 template <int W>
@@ -101,72 +108,34 @@ struct ReadSrc {
     const uint64_t *words;
     const uint64_t *woff;
     const uint32_t *len;
-    const uint64_t *koff;       // exclusive scan of k-mers per read (n_reads + 1)
-    const uint32_t *tile_read;  // first read of every tile
+    const uint64_t *coff;       // exclusive scan of chunks per read (n_reads + 1)
+    const uint32_t *tile_read;  // read holding the first chunk of every tile (ntiles + 1)
     uint64_t n_reads;
+    uint64_t n_chunks;
     int k;
 };
 
-// record j of the instance space -> canonical key (+ InOutMask bits).  `rl` is the caller's running
-// read cursor (index into s_koff): instances are visited in increasing order by a lane, so the read
-// is found by a short linear advance instead of a binary search per record.
-// s_rel[i] = koff[r0 + i] - koff[r0] (u32: a batch holds < 2^32 records), jr = j - koff[r0]
-template <int W, bool WITH_MASK>
-__device__ inline void read_record(const ReadSrc &S, uint32_t jr, const uint32_t *s_rel, uint32_t r0, uint32_t nr,
-                                   uint32_t &rl, Key<W> &key, uint32_t &val) {
-    while (rl + 1 < nr && s_rel[rl + 1] <= jr) ++rl;
-    const uint64_t r = (uint64_t)r0 + rl;
-    const uint32_t p = jr - s_rel[rl];
-    const uint64_t *rw = S.words + S.woff[r];
-    bool minimal;
-    if constexpr (W == 1) {
-        // the record exists, so the read holds at least p + k bases: its last word index follows
-        const uint32_t last_word = (S.len[r] - 1u) >> 5;
-        key = kmer_extract_canon1(rw, p, S.k, last_word, &minimal);
-    } else {
-        const Key<W> fwd = kmer_extract<W>(rw, p, S.k);
-        const Key<W> rc = kmer_rc<W>(fwd, S.k);
-        minimal = !kmer_less_nucl<W>(rc, fwd);
-        key = key_select<W>(minimal, fwd, rc);
-    }
-    if (WITH_MASK) {
-        const uint32_t L = S.len[r];
-        uint32_t m = 0;
-        if (p + (uint32_t)S.k < L) {
-            const uint32_t c = base_at(rw, p + (uint32_t)S.k);
-            m |= 1u << (minimal ? c : 7u - c);
-        }
-        if (p >= 1) {
-            const uint32_t c = base_at(rw, p - 1);
-            m |= 1u << (minimal ? 4u + c : 3u - c);
-        }
-        val = m;
-    }
-}
-
-// largest r in [0, nr) with s_rel[r] <= jr
-__device__ inline uint32_t read_of(const uint32_t *s_rel, uint32_t nr, uint32_t jr) {
+// largest r in [0, nr) with s_rel[r] <= c
+__device__ inline uint32_t read_of(const int32_t *s_rel, uint32_t nr, int32_t c) {
     uint32_t lo = 0, hi = nr;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (s_rel[mid] <= jr) lo = mid;
+        if (s_rel[mid] <= c) lo = mid;
         else hi = mid;
     }
     return lo;
 }
 
-
-// first read of every tile of the instance space
-__global__ void k_tile_reads(const uint64_t *__restrict__ koff, uint64_t n_reads, uint64_t n_tiles, uint32_t tile,
+// read holding the first unit (chunk) of every tile: largest r with off[r] <= t * tile
+__global__ void k_tile_reads(const uint64_t *__restrict__ off, uint64_t n_reads, uint64_t n_tiles, uint32_t tile,
                              uint32_t *__restrict__ tile_read) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
     const uint64_t j = t * (uint64_t)tile;
-    // largest r with koff[r] <= j (koff[n_reads] = N)
     uint64_t lo = 0, hi = n_reads;
     while (hi - lo > 1) {
         const uint64_t mid = (lo + hi) >> 1;
-        if (koff[mid] <= j) lo = mid;
+        if (off[mid] <= j) lo = mid;
         else hi = mid;
     }
     tile_read[t] = (uint32_t)lo;
@@ -179,6 +148,8 @@ struct TileMap {
     const uint32_t *seg_off;         // record offset of every level-1 bin (nb1 + 1), level 2 only
     uint32_t nseg;
     uint64_t n;
+    uint32_t ntiles;  // tiles of the level
+    uint32_t group;   // histogram kernels: consecutive tiles one workgroup walks
 };
 
 __device__ inline void tile_range(const TileMap &M, uint32_t tile, uint32_t kPartTile, uint32_t *seg, uint64_t *begin,
@@ -203,182 +174,21 @@ __device__ inline void tile_range(const TileMap &M, uint32_t tile, uint32_t kPar
     *count = (e - b) < (uint64_t)kPartTile ? (uint32_t)(e - b) : (uint32_t)kPartTile;
 }
 
-// SRC 0: key array, SRC 1: reads.  HIST_ONLY: accumulate the level histogram; else scatter.
-constexpr int kRelSlots = 1024;  // reads of one tile cached in LDS (150 bp reads: ~64 per tile)
-
-// LVL1: level-1 kernels have at most 512 bins (smaller LDS tables: two workgroups per CU)
-template <int W, int SRC, bool HAS_VAL, bool HIST_ONLY, bool LVL1>
-__global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__restrict__ in, const uint32_t *__restrict__ vin,
-                                                      ReadSrc S, TileMap M, PartLevel L,
-                                                      uint32_t *__restrict__ ghist,    // HIST_ONLY: [nseg * nb]
-                                                      uint32_t *__restrict__ cursor,   // scatter: [nseg * nb] running offsets
-                                                      Key<W> *__restrict__ out, uint32_t *__restrict__ vout) {
-    constexpr int kPartItems = PartCfg<W, SRC>::ITEMS, kPartTile = PartCfg<W, SRC>::TILE,
-                  kPartThreads = PartCfg<W, SRC>::THREADS;
-    constexpr int MAXB = LVL1 ? 512 : kMaxBins;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: lhist[MAXB] | lstart[MAXB] | goff[MAXB] | scan[32] | rel[kRelSlots] (SRC 1) | stage | vstage
-    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *lstart = lhist + MAXB;
-    uint32_t *goff = lstart + MAXB;
-    uint32_t *scan_tmp = goff + MAXB;
-    uint32_t *s_rel = scan_tmp + 32;
-    unsigned char *after = reinterpret_cast<unsigned char *>(s_rel) + (SRC == 1 ? sizeof(uint32_t) * kRelSlots : 0);
-    Key<W> *stage = reinterpret_cast<Key<W> *>(after);
-    uint32_t *vstage = reinterpret_cast<uint32_t *>(after + sizeof(Key<W>) * kPartTile);
-
+// Common tail of the scatter kernels.  On entry lhist[b] = records of bin b in this tile and binrank[i] =
+// bin << 16 | rank-in-bin (0xFFFFFFFF: no record).  One global atomicAdd per non-empty bin reserves the
+// tile's run in that bin; the records are reordered through LDS (stage) so that a wave stores contiguous
+// per-bin runs.
+template <int W, int ITEMS, int THREADS, int MAXB, bool HAS_VAL>
+__device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uint32_t (&vals)[ITEMS],
+                                          const uint32_t (&binrank)[ITEMS], uint32_t *lhist, uint32_t *lstart,
+                                          uint32_t *goff, uint32_t *scan_tmp, Key<W> *stage, uint32_t *vstage,
+                                          uint32_t nb, uint64_t gbin0, const PartLevel &L,
+                                          uint32_t *__restrict__ cursor, Key<W> *__restrict__ out,
+                                          uint32_t *__restrict__ vout) {
     const int tid = threadIdx.x;
-    uint32_t seg, count;
-    uint64_t begin;
-    tile_range(M, blockIdx.x, (uint32_t)kPartTile, &seg, &begin, &count);
-    const uint32_t nb = (L.level == 1) ? L.nb1 : L.seg_nb2[seg];
-    const uint64_t gbin0 = (L.level == 1) ? 0ull : (uint64_t)L.seg_bin_start[seg];  // flat index of bin 0
-
-    for (uint32_t b = tid; b < nb; b += kPartThreads) lhist[b] = 0;
-    uint32_t r0 = 0, nr = 0;
-    bool cached = true;  // SRC 1: the tile's reads fit the LDS cursor table (else: slow path on global koff)
-    uint64_t k0 = 0;  // koff of the tile's first read
-    if (SRC == 1) {
-        r0 = S.tile_read[blockIdx.x];
-        const uint32_t r1 = S.tile_read[blockIdx.x + 1];
-        nr = r1 - r0 + 1;  // reads r0..r1 inclusive
-        cached = nr + 1 <= (uint32_t)kRelSlots;
-        k0 = S.koff[r0];
-        if (cached)
-            for (uint32_t i = tid; i <= nr; i += kPartThreads)
-                s_rel[i] = (r0 + i <= S.n_reads) ? (uint32_t)(S.koff[r0 + i] - k0) : 0xFFFFFFFFu;
-    }
-    __syncthreads();
-
-    Key<W> keys[kPartItems];
-    uint32_t vals[kPartItems];
-    uint32_t binrank[kPartItems];  // bin << 16 | rank (rank < 8192 fits 13 bits; bins < 1024)
-    // Record owned by (item i, this thread).  Key arrays are read striped over the block (coalesced
-    // 8/16-byte loads).  Reads are walked blocked: a lane owns ITEMS consecutive k-mer positions, so
-    // after the first one every k-mer is ROLLED from its predecessor (8-byte keys): with
-    // R = rev2(fwd) kept alongside, one step is fwd = fwd>>2 | b<<2(k-1), R = R<<2 | b<<2(32-k), the
-    // reverse complement is (~R)>>pad and the canonical test is R <= (~fwd)<<pad -- ~15 integer ops
-    // instead of a fresh extraction + bit reversal per position.
-    const uint32_t jbase = (uint32_t)(begin - k0);  // SRC 1: tile start relative to its first read
-    uint32_t rl = 0, nxt = 0;
-    bool have = false;
-    const uint64_t *rw = nullptr;
-    uint32_t Lr = 0, rstart = 0;
-    uint64_t fwd = 0, Rv = 0, wcur = 0;
-    if (SRC == 1 && cached) {
-        const uint32_t first = (uint32_t)tid * kPartItems;
-        if (first < count) rl = read_of(s_rel, nr, jbase + first);
-        nxt = s_rel[rl + 1];
-        rstart = s_rel[rl];
-    }
-#pragma unroll
-    for (int i = 0; i < kPartItems; ++i) {
-        const uint32_t local = (SRC == 1) ? (uint32_t)(tid * kPartItems + i) : (uint32_t)(i * kPartThreads + tid);
-        const bool valid = local < count;
-#pragma unroll
-        for (int w = 0; w < W; ++w) keys[i].w[w] = 0;
-        vals[i] = 0;
-        binrank[i] = 0xFFFFFFFFu;
-        if (valid) {
-            if (SRC == 0) {
-                keys[i] = key_load<W>(&in[begin + local]);
-                if (HAS_VAL) vals[i] = vin[begin + local];
-            } else if (!cached) {
-                // many tiny reads in one tile: locate every record by a search on the global table
-                const uint64_t j = begin + local;
-                uint64_t lo = r0, hi = (uint64_t)r0 + nr;
-                while (hi - lo > 1) {
-                    const uint64_t mid = (lo + hi) >> 1;
-                    if (S.koff[mid] <= j) lo = mid;
-                    else hi = mid;
-                }
-                const uint32_t p = (uint32_t)(j - S.koff[lo]);
-                const uint64_t *rw2 = S.words + S.woff[lo];
-                const Key<W> f2 = kmer_extract<W>(rw2, p, S.k);
-                const Key<W> c2 = kmer_rc<W>(f2, S.k);
-                const bool min2 = !kmer_less_nucl<W>(c2, f2);
-                keys[i] = key_select<W>(min2, f2, c2);
-                if (HAS_VAL) {
-                    const uint32_t L2 = S.len[lo];
-                    uint32_t m = 0;
-                    if (p + (uint32_t)S.k < L2) {
-                        const uint32_t c = base_at(rw2, p + (uint32_t)S.k);
-                        m |= 1u << (min2 ? c : 7u - c);
-                    }
-                    if (p >= 1) {
-                        const uint32_t c = base_at(rw2, p - 1);
-                        m |= 1u << (min2 ? 4u + c : 3u - c);
-                    }
-                    vals[i] = m;
-                }
-            } else if constexpr (W == 1) {
-                const uint32_t jr = jbase + local;
-                if (jr >= nxt) {  // crossed into a later read
-                    while (rl + 1 < nr && s_rel[rl + 1] <= jr) ++rl;
-                    nxt = s_rel[rl + 1];
-                    rstart = s_rel[rl];
-                    have = false;
-                }
-                const uint32_t p = jr - rstart;
-                const uint32_t k_ = (uint32_t)S.k, pad = 64u - 2u * k_;
-                if (!have) {
-                    const uint64_t r = (uint64_t)r0 + rl;
-                    rw = S.words + S.woff[r];
-                    Lr = S.len[r];
-                    const uint32_t wi = p >> 5, sh = (p & 31u) << 1, lastw = (Lr - 1u) >> 5;
-                    const uint64_t lo = rw[wi];
-                    const uint64_t hi = rw[wi + 1 <= lastw ? wi + 1 : lastw];
-                    fwd = (lo >> sh) | ((hi << 1) << (63u - sh));
-                    fwd = (fwd << pad) >> pad;
-                    Rv = rev2(fwd);
-                    wcur = rw[(p + k_ - 1u) >> 5];
-                    have = true;
-                } else {
-                    const uint32_t q = p + k_ - 1u;  // the base that enters
-                    if ((q & 31u) == 0) wcur = rw[q >> 5];
-                    const uint64_t b = (wcur >> ((q & 31u) << 1)) & 3ull;
-                    fwd = (fwd >> 2) | (b << (2u * (k_ - 1u)));
-                    Rv = (Rv << 2) | (b << pad);
-                }
-                const bool minimal = Rv <= ((~fwd) << pad);
-                keys[i].w[0] = minimal ? fwd : ((~Rv) >> pad);
-                if (HAS_VAL) {
-                    uint32_t m = 0;
-                    if (p + k_ < Lr) {
-                        const uint32_t c = base_at(rw, p + k_);
-                        m |= 1u << (minimal ? c : 7u - c);
-                    }
-                    if (p >= 1) {
-                        const uint32_t c = base_at(rw, p - 1);
-                        m |= 1u << (minimal ? 4u + c : 3u - c);
-                    }
-                    vals[i] = m;
-                }
-            } else {
-                read_record<W, HAS_VAL>(S, jbase + local, s_rel, r0, nr, rl, keys[i], vals[i]);
-            }
-            uint32_t pfx = prefix_of<W>(keys[i], L.dmode, L.w0bits);
-            if (select_prefix(pfx, L)) {
-                const uint32_t b = bin_of(pfx, L, nb);
-                const uint32_t rank = atomicAdd(&lhist[b], 1u);
-                binrank[i] = (b << 16) | rank;
-            }
-        }
-    }
-    __syncthreads();
-
-    if (HIST_ONLY) {
-        for (uint32_t b = tid; b < nb; b += kPartThreads) {
-            const uint32_t c = lhist[b];
-            if (c) atomicAdd(&ghist[gbin0 + b], c);
-        }
-        return;
-    }
-
-    // exclusive scan of the local histogram (<= 1024 bins; BPT bins per thread)
     uint32_t staged = 0;
     {
-        constexpr int BPT = (MAXB + kPartThreads - 1) / kPartThreads;
+        constexpr int BPT = (MAXB + THREADS - 1) / THREADS;
         uint32_t c[BPT];
         uint32_t v = 0;
 #pragma unroll
@@ -397,11 +207,11 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
         if (lane == 63) scan_tmp[wave] = incl;
         __syncthreads();
         uint32_t wbase = 0, all = 0;
-        for (int w = 0; w < kPartThreads / 64; ++w) {
+        for (int w = 0; w < THREADS / 64; ++w) {
             if (w < wave) wbase += scan_tmp[w];
             all += scan_tmp[w];
         }
-        staged = all;  // records of this tile that take part (== count unless a range pass filters)
+        staged = all;  // records of this tile that take part
         uint32_t ex = wbase + incl - v;
 #pragma unroll
         for (int q = 0; q < BPT; ++q) {
@@ -416,7 +226,7 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
     __syncthreads();
 
 #pragma unroll
-    for (int i = 0; i < kPartItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         if (binrank[i] != 0xFFFFFFFFu) {
             const uint32_t pos = lstart[binrank[i] >> 16] + (binrank[i] & 0xFFFFu);
             key_store<W>(&stage[pos], keys[i]);
@@ -426,8 +236,8 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
     __syncthreads();
 
 #pragma unroll
-    for (int i = 0; i < kPartItems; ++i) {
-        const uint32_t pos = (uint32_t)(i * kPartThreads + tid);
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t pos = (uint32_t)(i * THREADS + tid);
         if (pos < staged) {
             const Key<W> key = key_load<W>(&stage[pos]);
             uint32_t pfx = prefix_of<W>(key, L.dmode, L.w0bits);
@@ -440,10 +250,328 @@ __global__ __launch_bounds__(part_threads(SRC)) void k_part(const Key<W> *__rest
     }
 }
 
-static size_t part_smem(int W, int tile, int src, bool has_val, bool hist_only, bool lvl1) {
-    size_t s = sizeof(uint32_t) * (3 * (lvl1 ? 512 : kMaxBins) + 32) + (src == 1 ? sizeof(uint32_t) * kRelSlots : 0);
+// One partition level over a key array.  HIST_ONLY: accumulate the level histogram; else scatter.
+// LVL1: level-1 kernels have at most 512 bins (smaller LDS tables: two workgroups per CU)
+template <int W, bool HAS_VAL, bool HIST_ONLY, bool LVL1>
+__global__ __launch_bounds__(PartCfg<W>::THREADS) void k_part(const Key<W> *__restrict__ in,
+                                                              const uint32_t *__restrict__ vin, TileMap M, PartLevel L,
+                                                              uint32_t *__restrict__ ghist,   // HIST_ONLY: [nseg * nb]
+                                                              uint32_t *__restrict__ cursor,  // scatter: running offsets
+                                                              Key<W> *__restrict__ out, uint32_t *__restrict__ vout) {
+    constexpr int kPartItems = PartCfg<W>::ITEMS, kPartTile = PartCfg<W>::TILE, kPartThreads = PartCfg<W>::THREADS;
+    constexpr int MAXB = LVL1 ? 512 : kMaxBins;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: lhist[MAXB] | lstart[MAXB] | goff[MAXB] | scan[32] | stage | vstage
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *lstart = lhist + MAXB;
+    uint32_t *goff = lstart + MAXB;
+    uint32_t *scan_tmp = goff + MAXB;
+    unsigned char *after = reinterpret_cast<unsigned char *>(scan_tmp + 32);
+    Key<W> *stage = reinterpret_cast<Key<W> *>(after);
+    uint32_t *vstage = reinterpret_cast<uint32_t *>(after + sizeof(Key<W>) * kPartTile);
+
+    const int tid = threadIdx.x;
+    if constexpr (HIST_ONLY) {
+        // a workgroup walks `group` consecutive tiles and adds its LDS histogram to the global one when the
+        // level-1 segment changes and at the end: one global atomic per (workgroup, bin), not per (tile, bin)
+        const uint32_t t0 = blockIdx.x * M.group;
+        const uint32_t t1 = t0 + M.group < M.ntiles ? t0 + M.group : M.ntiles;
+        uint32_t cur = 0xFFFFFFFFu, nb = 0;
+        uint64_t gbin0 = 0;
+        for (uint32_t t = t0; t < t1; ++t) {
+            uint32_t seg, count;
+            uint64_t begin;
+            tile_range(M, t, (uint32_t)kPartTile, &seg, &begin, &count);
+            if (seg != cur) {
+                __syncthreads();
+                for (uint32_t b = tid; b < nb; b += kPartThreads) {
+                    const uint32_t c = lhist[b];
+                    if (c) atomicAdd(&ghist[gbin0 + b], c);
+                }
+                __syncthreads();
+                cur = seg;
+                nb = (L.level == 1) ? L.nb1 : L.seg_nb2[seg];
+                gbin0 = (L.level == 1) ? 0ull : (uint64_t)L.seg_bin_start[seg];
+                for (uint32_t b = tid; b < nb; b += kPartThreads) lhist[b] = 0;
+                __syncthreads();
+            }
+#pragma unroll
+            for (int i = 0; i < kPartItems; ++i) {
+                const uint32_t local = (uint32_t)(i * kPartThreads + tid);
+                if (local < count) {
+                    const Key<W> key = key_load<W>(&in[begin + local]);
+                    uint32_t pfx = prefix_of<W>(key, L.dmode, L.w0bits);
+                    if (select_prefix(pfx, L)) atomicAdd(&lhist[bin_of(pfx, L, nb)], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < nb; b += kPartThreads) {
+            const uint32_t c = lhist[b];
+            if (c) atomicAdd(&ghist[gbin0 + b], c);
+        }
+        return;
+    }
+    uint32_t seg, count;
+    uint64_t begin;
+    tile_range(M, blockIdx.x, (uint32_t)kPartTile, &seg, &begin, &count);
+    const uint32_t nb = (L.level == 1) ? L.nb1 : L.seg_nb2[seg];
+    const uint64_t gbin0 = (L.level == 1) ? 0ull : (uint64_t)L.seg_bin_start[seg];  // flat index of bin 0
+
+    for (uint32_t b = tid; b < nb; b += kPartThreads) lhist[b] = 0;
+    __syncthreads();
+
+    Key<W> keys[kPartItems];
+    uint32_t vals[kPartItems];
+    uint32_t binrank[kPartItems];  // bin << 16 | rank (rank < 8192 fits 13 bits; bins < 1024)
+    // striped over the block: coalesced 8/16-byte loads
+#pragma unroll
+    for (int i = 0; i < kPartItems; ++i) {
+        const uint32_t local = (uint32_t)(i * kPartThreads + tid);
+#pragma unroll
+        for (int w = 0; w < W; ++w) keys[i].w[w] = 0;
+        vals[i] = 0;
+        binrank[i] = 0xFFFFFFFFu;
+        if (local < count) {
+            keys[i] = key_load<W>(&in[begin + local]);
+            if (HAS_VAL) vals[i] = vin[begin + local];
+            uint32_t pfx = prefix_of<W>(keys[i], L.dmode, L.w0bits);
+            if (select_prefix(pfx, L)) {
+                const uint32_t b = bin_of(pfx, L, nb);
+                const uint32_t rank = atomicAdd(&lhist[b], 1u);
+                binrank[i] = (b << 16) | rank;
+            }
+        }
+    }
+    __syncthreads();
+    part_tail<W, kPartItems, kPartThreads, MAXB, HAS_VAL>(keys, vals, binrank, lhist, lstart, goff, scan_tmp, stage, vstage,
+                                                        nb, gbin0, L, cursor, out, vout);
+}
+
+static size_t part_smem(int W, int tile, bool has_val, bool hist_only, bool lvl1) {
+    size_t s = sizeof(uint32_t) * (3 * (lvl1 ? 512 : kMaxBins) + 32);
     if (!hist_only) s += (size_t)W * 8 * tile + (has_val ? 4 * (size_t)tile : 0);
     return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused k-mer extraction + level-1 partition over packed reads (HASH prefix)
+// ------------------------------------------------------------------------------------------
+// Instance space = chunks: read r contributes ceil(nk_r / CH) chunks of CH consecutive k-mer positions
+// (the last one shorter); a lane owns one chunk, so it never crosses a read: one extraction, then (8-byte
+// keys) every further k-mer is ROLLED from its predecessor -- with R = rev2(fwd) kept alongside one step is
+// fwd = fwd>>2 | b<<2(k-1), R = R<<2 | b<<2(32-k), the reverse complement is (~R)>>pad and the canonical
+// test is R <= (~fwd)<<pad: ~15 integer ops instead of a fresh extraction + bit reversal.
+// The tile's reads (cursor tables + packed words, one coalesced copy) are staged in LDS first, so the lanes'
+// dependent lookups (read of the chunk -> word offset -> words) cost LDS, not HBM, latency.  A tile whose
+// reads do not fit (thousands of reads shorter than k in a row, words not laid out in read order) takes
+// the same code over the global arrays.
+struct ChunkWords {
+    const uint64_t *rw;  // words of the chunk's read (LDS or global)
+    uint32_t p;          // first k-mer position of the chunk
+    uint32_t cnt;        // k-mers of the chunk (0: idle lane)
+    uint32_t len;        // read length
+};
+
+// 64 bits of the packed read starting at base p (bases p .. p+31; words past `lastw` are not touched)
+__device__ __forceinline__ uint64_t bases_from(const uint64_t *rw, uint32_t p, uint32_t lastw) {
+    uint32_t wi = p >> 5;
+    wi = wi <= lastw ? wi : lastw;
+    const uint32_t sh = (p & 31u) << 1;
+    const uint64_t lo = rw[wi];
+    const uint64_t hi = rw[wi + 1 <= lastw ? wi + 1 : lastw];
+    return (lo >> sh) | ((hi << 1) << (63u - sh));
+}
+
+template <int W, int CH, bool HAS_VAL>
+__device__ __forceinline__ void chunk_records(const ChunkWords C, uint32_t k_, const PartLevel &L, uint32_t nb,
+                                              uint32_t *lhist, Key<W> (&keys)[CH], uint32_t (&vals)[CH],
+                                              uint32_t (&binrank)[CH]) {
+    const uint64_t *rw = C.rw;
+    // 8-byte keys, all state top-aligned so that every per-step shift is by a constant:
+    //   Ft = fwd << pad (base 0 at bit pad, base k-1 at bits 62..63), Rv = rev2(fwd) (base 0 at the top)
+    //   step: Ft = (Ft >> 2) & himask | b << 62,  Rv = Rv << 2 | b << pad
+    //   canonical test (base-lexicographic fwd <= rc, rtseq.hpp:407-415): Rv <= ~Ft & himask
+    const uint32_t pad = W == 1 ? 64u - 2u * k_ : 0u;
+    const uint64_t himask = ~0ull << pad;
+    uint64_t Ft = 0, Rv = 0;
+    uint32_t inb = 0;    // bases p+k, p+k+1, ...: the ones that enter (and the outgoing-edge bases)
+    uint32_t prevb = 0;  // bases p-1, p, ...: the incoming-edge bases
+    if (W == 1 && C.cnt) {
+        const uint32_t lastw = (C.len - 1u) >> 5;
+        const uint64_t f = bases_from(rw, C.p, lastw);
+        Ft = f << pad;
+        Rv = rev2(Ft >> pad);
+        inb = (uint32_t)bases_from(rw, C.p + k_, lastw);
+        if (HAS_VAL) prevb = ((uint32_t)f << 2) | (C.p ? base_at(rw, C.p - 1u) : 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) keys[i].w[w] = 0;
+        vals[i] = 0;
+        binrank[i] = 0xFFFFFFFFu;
+        if ((uint32_t)i < C.cnt) {
+            const uint32_t p = C.p + (uint32_t)i;
+            bool minimal;
+            uint32_t nextc, prevc;  // HAS_VAL: bases p+k and p-1
+            if constexpr (W == 1) {
+                if (i > 0) {
+                    const uint64_t b = (inb >> (2 * (i - 1))) & 3u;
+                    Ft = ((Ft >> 2) & himask) | (b << 62);
+                    Rv = (Rv << 2) | (b << pad);
+                }
+                minimal = Rv <= (~Ft & himask);
+                keys[i].w[0] = (minimal ? Ft : ~Rv) >> pad;
+                nextc = (inb >> (2 * i)) & 3u;
+                prevc = (prevb >> (2 * i)) & 3u;
+            } else {
+                const Key<W> f = kmer_extract<W>(rw, p, (int)k_);
+                const Key<W> rc = kmer_rc<W>(f, (int)k_);
+                minimal = !kmer_less_nucl<W>(rc, f);
+                keys[i] = key_select<W>(minimal, f, rc);
+                if (HAS_VAL) {
+                    nextc = p + k_ < C.len ? base_at(rw, p + k_) : 0u;
+                    prevc = p >= 1 ? base_at(rw, p - 1) : 0u;
+                }
+            }
+            if (HAS_VAL) {
+                uint32_t m = 0;
+                if (p + k_ < C.len) m |= 1u << (minimal ? nextc : 7u - nextc);
+                if (p >= 1) m |= 1u << (minimal ? 4u + prevc : 3u - prevc);
+                vals[i] = m;
+            }
+            uint32_t pfx = part_hash32<W>(keys[i]);
+            if (select_prefix(pfx, L)) {
+                const uint32_t b = L.b1 == 0 ? 0u : (pfx >> (32 - L.b1));
+                const uint32_t rank = atomicAdd(&lhist[b], 1u);
+                binrank[i] = (b << 16) | rank;
+            }
+        }
+    }
+}
+
+template <int W, bool HAS_VAL, bool HIST_ONLY>
+__global__ __launch_bounds__(kRdThreads) void k_part_reads(ReadSrc S, PartLevel L, uint32_t *__restrict__ ghist,
+                                                           uint32_t *__restrict__ cursor, Key<W> *__restrict__ out,
+                                                           uint32_t *__restrict__ vout) {
+    constexpr int CH = RdCfg<W>::CH, TILE = RdCfg<W>::TILE, MAXB = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: lhist | lstart | goff | scan[32] | U, where U is the read tables while extracting
+    // (rel[kRdSlots+2] | wrel[kRdSlots+2] | nk[kRdSlots+2] | words[kRdWords+W+2]) and the stage afterwards
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *lstart = lhist + MAXB;
+    uint32_t *goff = lstart + MAXB;
+    uint32_t *scan_tmp = goff + MAXB;
+    unsigned char *U = reinterpret_cast<unsigned char *>(scan_tmp + 32);
+    int32_t *s_rel = reinterpret_cast<int32_t *>(U);  // first chunk of read r0+i, relative to the tile's first chunk
+    int32_t *s_wrel = s_rel + (kRdSlots + 2);         // first word of read r0+i, relative to the staged window
+    uint32_t *s_len = reinterpret_cast<uint32_t *>(s_wrel + (kRdSlots + 2));
+    uint64_t *s_words = reinterpret_cast<uint64_t *>(s_len + (kRdSlots + 2));
+    Key<W> *stage = reinterpret_cast<Key<W> *>(U);
+    uint32_t *vstage = reinterpret_cast<uint32_t *>(U + sizeof(Key<W>) * TILE);
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k_ = (uint32_t)S.k;
+    const uint32_t nb = L.nb1;
+    const uint32_t ntiles = (uint32_t)((S.n_chunks + kRdThreads - 1) / kRdThreads);
+    for (uint32_t b = tid; b < nb; b += kRdThreads) lhist[b] = 0;
+
+    // scatter: one tile per workgroup (grid == tiles).  Histogram: a workgroup walks many tiles and adds
+    // its LDS histogram to the global one once (512 atomics per workgroup instead of per tile).
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint64_t c0 = (uint64_t)tile * kRdThreads;  // first chunk of the tile
+    const uint64_t left = S.n_chunks - c0;
+    const uint32_t nch = left < (uint64_t)kRdThreads ? (uint32_t)left : (uint32_t)kRdThreads;
+    const uint32_t r0 = S.tile_read[tile], r1 = S.tile_read[tile + 1];
+    const uint32_t nr = r1 - r0 + 1;  // reads r0..r1 inclusive
+
+    // staged word window: from the word of the first base this tile touches in r0 (one base before the
+    // chunk for the incoming-edge bit) to the last word it can touch in r1
+    const uint32_t p0 = (uint32_t)(c0 - S.coff[r0]) * CH;
+    const uint64_t w_r0 = S.woff[r0], w_r1 = S.woff[r1];
+    const uint64_t wbase = w_r0 + ((p0 ? p0 - 1u : 0u) >> 5);
+    const uint32_t len1 = S.len[r1];
+    const uint64_t span1 = (c0 + kRdThreads - S.coff[r1]) * CH + k_;  // base index the tile can reach in r1
+    const uint32_t lastb1 = len1 ? (uint32_t)(span1 < (uint64_t)(len1 - 1u) ? span1 : (uint64_t)(len1 - 1u)) : 0u;
+    const uint64_t wend = w_r1 + (len1 ? (lastb1 >> 5) + 1u : 0u);
+    bool fast = nr <= (uint32_t)kRdSlots && wend >= wbase && wend - wbase <= (uint64_t)kRdWords;
+    const uint32_t wspan = fast ? (uint32_t)(wend - wbase) : 0u;
+    if (fast) {
+        bool bad = false;
+        for (uint32_t i = tid; i <= nr; i += kRdThreads) {
+            const uint64_t rr = (uint64_t)r0 + i;  // <= n_reads (coff holds n_reads + 1 entries)
+            s_rel[i] = (int32_t)(int64_t)(S.coff[rr] - c0);
+            if (i < nr) {
+                const uint64_t wo = S.woff[rr];
+                const uint32_t ln = S.len[rr];
+                s_wrel[i] = (int32_t)(int64_t)(wo - wbase);
+                s_len[i] = ln;
+                // words must be laid out in read order: every read starts inside the window and all but
+                // the last end inside it
+                if (i > 0 && wo < wbase) bad = true;
+                if (i + 1 < nr && wo + ((ln + 31u) >> 5) > wend) bad = true;
+            }
+        }
+        for (uint32_t i = tid; i < wspan; i += kRdThreads) s_words[i] = S.words[wbase + i];
+        fast = !__syncthreads_or(bad);
+    } else {
+        __syncthreads();
+    }
+
+    Key<W> keys[CH];
+    uint32_t vals[CH];
+    uint32_t binrank[CH];  // bin << 16 | rank (rank < 8192 fits 13 bits; bins < 512)
+    if (fast) {
+        ChunkWords C{s_words, 0, 0, 0};
+        if (tid < nch) {
+            const uint32_t ri = read_of(s_rel, nr, (int32_t)tid);
+            C.p = (uint32_t)((int32_t)tid - s_rel[ri]) * CH;
+            C.len = s_len[ri];
+            const uint32_t nk = C.len - k_ + 1u;  // the read owns a chunk, so len >= k
+            C.cnt = nk - C.p < (uint32_t)CH ? nk - C.p : (uint32_t)CH;
+            C.rw = s_words + s_wrel[ri];
+        }
+        chunk_records<W, CH, HAS_VAL>(C, k_, L, nb, lhist, keys, vals, binrank);
+    } else {
+        ChunkWords C{S.words, 0, 0, 0};
+        if (tid < nch) {
+            const uint64_t c = c0 + tid;
+            uint64_t lo = r0, hi = (uint64_t)r0 + nr;  // largest r with coff[r] <= c
+            while (hi - lo > 1) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (S.coff[mid] <= c) lo = mid;
+                else hi = mid;
+            }
+            C.p = (uint32_t)(c - S.coff[lo]) * CH;
+            C.len = S.len[lo];
+            const uint32_t nk = C.len - k_ + 1u;
+            C.cnt = nk - C.p < (uint32_t)CH ? nk - C.p : (uint32_t)CH;
+            C.rw = S.words + S.woff[lo];
+        }
+        chunk_records<W, CH, HAS_VAL>(C, k_, L, nb, lhist, keys, vals, binrank);
+    }
+    __syncthreads();  // histogram complete / the read tables may be overwritten
+
+    if constexpr (!HIST_ONLY) {
+        part_tail<W, CH, kRdThreads, MAXB, HAS_VAL>(keys, vals, binrank, lhist, lstart, goff, scan_tmp, stage, vstage, nb,
+                                                    0ull, L, cursor, out, vout);
+        return;
+    }
+    }
+    if (HIST_ONLY) {
+        for (uint32_t b = tid; b < nb; b += kRdThreads) {
+            const uint32_t c = lhist[b];
+            if (c) atomicAdd(&ghist[b], c);
+        }
+    }
+}
+
+static size_t part_reads_smem(int W, bool has_val, bool hist_only) {
+    const size_t tables = sizeof(uint32_t) * 3 * (kRdSlots + 2) + sizeof(uint64_t) * (kRdWords + W + 2);
+    const size_t tile = (size_t)kRdThreads * (W == 1 ? 8 : 4);
+    const size_t stage = hist_only ? 0 : (size_t)W * 8 * tile + (has_val ? 4 * tile : 0);
+    return sizeof(uint32_t) * (3 * 512 + 32) + std::max(tables, stage);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -969,11 +1097,15 @@ __global__ void k_scan_to_u32(const uint64_t *__restrict__ in, uint64_t n, uint6
     if (i == n) out[n] = (uint32_t)total;
 }
 
-__global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, uint64_t n, uint32_t k, uint64_t *__restrict__ nk) {
+// k-mers and chunks (of ch k-mer positions) of every read
+__global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, uint64_t n, uint32_t k, uint32_t ch,
+                                  uint64_t *__restrict__ nk, uint64_t *__restrict__ nch) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const uint32_t L = len[i];
-        nk[i] = L >= k ? (uint64_t)(L - k + 1) : 0ull;
+        const uint64_t c = L >= k ? (uint64_t)(L - k + 1) : 0ull;
+        nk[i] = c;
+        nch[i] = (c + ch - 1) / ch;
     }
 }
 
@@ -1007,24 +1139,43 @@ struct MsdRunner {
     int op;        // MSD_OP_*
     bool in_vals;  // records carry a payload from the start (mask extraction or input counts)
 
-    template <int SRC, bool HAS_VAL, bool HIST>
-    void launch_part(const char *fam, double bytes, uint32_t ntiles, const Key<W> *in, const uint32_t *vin, ReadSrc S,
-                     TileMap M, PartLevel L, uint32_t *ghist, uint32_t *cursor, Key<W> *out, uint32_t *vout) {
-        if (L.level == 1) launch_part_l<SRC, HAS_VAL, HIST, true>(fam, bytes, ntiles, in, vin, S, M, L, ghist, cursor, out, vout);
-        else launch_part_l<SRC, HAS_VAL, HIST, false>(fam, bytes, ntiles, in, vin, S, M, L, ghist, cursor, out, vout);
+    template <bool HAS_VAL, bool HIST>
+    void launch_part(const char *fam, double bytes, uint32_t ntiles, const Key<W> *in, const uint32_t *vin, TileMap M,
+                     PartLevel L, uint32_t *ghist, uint32_t *cursor, Key<W> *out, uint32_t *vout) {
+        if (L.level == 1) launch_part_l<HAS_VAL, HIST, true>(fam, bytes, ntiles, in, vin, M, L, ghist, cursor, out, vout);
+        else launch_part_l<HAS_VAL, HIST, false>(fam, bytes, ntiles, in, vin, M, L, ghist, cursor, out, vout);
     }
 
-    template <int SRC, bool HAS_VAL, bool HIST, bool LVL1>
-    void launch_part_l(const char *fam, double bytes, uint32_t ntiles, const Key<W> *in, const uint32_t *vin, ReadSrc S,
-                       TileMap M, PartLevel L, uint32_t *ghist, uint32_t *cursor, Key<W> *out, uint32_t *vout) {
+    template <bool HAS_VAL, bool HIST, bool LVL1>
+    void launch_part_l(const char *fam, double bytes, uint32_t ntiles, const Key<W> *in, const uint32_t *vin, TileMap M,
+                       PartLevel L, uint32_t *ghist, uint32_t *cursor, Key<W> *out, uint32_t *vout) {
         if (ntiles == 0) return;
-        const size_t sm = part_smem(W, PartCfg<W, SRC>::TILE, SRC, HAS_VAL, HIST, LVL1);
-        auto fn = k_part<W, SRC, HAS_VAL, HIST, LVL1>;
+        const size_t sm = part_smem(W, PartCfg<W>::TILE, HAS_VAL, HIST, LVL1);
+        auto fn = k_part<W, HAS_VAL, HIST, LVL1>;
         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)sm));
+        M.ntiles = ntiles;
+        M.group = HIST ? 16u : 1u;
+        const uint32_t grid = (ntiles + M.group - 1) / M.group;
         KernelTimer t(ctx, fam, bytes);
-        hipLaunchKernelGGL(fn, dim3(ntiles), dim3(PartCfg<W, SRC>::THREADS), sm, ctx->stream, in, vin, S, M, L, ghist, cursor, out,
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(PartCfg<W>::THREADS), sm, ctx->stream, in, vin, M, L, ghist, cursor, out,
                            vout);
+        check_launch(fam);
+    }
+
+    template <bool HAS_VAL, bool HIST>
+    void launch_part_reads(const char *fam, double bytes, uint32_t ntiles, ReadSrc S, PartLevel L, uint32_t *ghist,
+                           uint32_t *cursor, Key<W> *out, uint32_t *vout) {
+        if (ntiles == 0) return;
+        const size_t sm = part_reads_smem(W, HAS_VAL, HIST);
+        auto fn = k_part_reads<W, HAS_VAL, HIST>;
+        BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sm));
+        // histogram: ~8 resident-workgroup rounds, each workgroup walks its tiles and flushes once
+        static const char *eg = getenv("BBK_HIST_GRID");
+        const uint32_t grid = HIST ? std::min<uint32_t>(ntiles, eg ? (uint32_t)atoi(eg) : 4096u) : ntiles;
+        KernelTimer t(ctx, fam, bytes);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(kRdThreads), sm, ctx->stream, S, L, ghist, cursor, out, vout);
         check_launch(fam);
     }
 
@@ -1117,25 +1268,29 @@ struct MsdRunner {
     // pass takes: *need_sel_bits says into how many hash ranges (2^bits) the caller must split (HASH mode).
     int run(const bbk_reads *rd, const void *d_keys, const uint32_t *d_vals, uint64_t n_in, bool with_mask,
             MsdOutput &out, int sel_bits = 0, uint32_t sel_val = 0, int *need_sel_bits = nullptr) {
-        constexpr uint32_t kPartTileK = PartCfg<W, 0>::TILE, kPartTileR = PartCfg<W, 1>::TILE;
+        constexpr uint32_t kPartTileK = PartCfg<W>::TILE;
         const bool from_reads = rd != nullptr;
         const bool has_val = with_mask || d_vals != nullptr;
         const size_t rec = (size_t)W * 8;
         const int w0bits = (W == 1) ? (int)(2 * k) : 64;
 
-        // ---- instance space
-        DevBuf koff, tile_read;
-        uint64_t N = n_in;
+        // ---- instance space (reads: k-mers for the sizes, chunks for the level-1 tiles)
+        DevBuf coff, tile_read;
+        uint64_t N = n_in, n_chunks = 0;
         if (from_reads) {
-            koff.alloc((rd->n + 1) * sizeof(uint64_t));
+            BBK_REQUIRE(dmode == MSD_HASH, BBK_ERR_INTERNAL, "reads are partitioned by hash prefix only");
+            DevBuf nk((rd->n + 1) * sizeof(uint64_t));
+            coff.alloc((rd->n + 1) * sizeof(uint64_t));
             if (rd->n) {
                 hipLaunchKernelGGL(k_kmers_per_read2, dim3((unsigned)((rd->n + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   rd->d_len, rd->n, k, koff.as<uint64_t>());
+                                   rd->d_len, rd->n, k, (uint32_t)RdCfg<W>::CH, nk.as<uint64_t>(), coff.as<uint64_t>());
                 check_launch("k_kmers_per_read2");
             }
-            N = exclusive_scan_u64(ctx, koff.as<uint64_t>(), koff.as<uint64_t>(), rd->n);
-            BBK_HIP(hipMemcpyAsync(koff.as<uint64_t>() + rd->n, &N, sizeof(uint64_t), hipMemcpyHostToDevice,
+            N = exclusive_scan_u64(ctx, nk.as<uint64_t>(), nk.as<uint64_t>(), rd->n);
+            n_chunks = exclusive_scan_u64(ctx, coff.as<uint64_t>(), coff.as<uint64_t>(), rd->n);
+            BBK_HIP(hipMemcpyAsync(coff.as<uint64_t>() + rd->n, &n_chunks, sizeof(uint64_t), hipMemcpyHostToDevice,
                                    ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));  // n_chunks is a stack variable
         }
         out.instances = N;
         out.n = 0;
@@ -1144,7 +1299,6 @@ struct MsdRunner {
             out.vals.alloc(16);
             return 1;
         }
-        const uint32_t kPartTile1 = from_reads ? kPartTileR : kPartTileK;  // level-1 tile of this call
         BBK_REQUIRE(N < (1ull << 32) - kPartTileK, BBK_ERR_ARG,
                     "batch holds %llu records; a single device batch is limited to 2^32-1 (split the input)",
                     (unsigned long long)N);
@@ -1174,16 +1328,19 @@ struct MsdRunner {
         PartLevel L1{1, b1, nb1, dmode, w0bits, nullptr, nullptr, sel_bits, sel_val};
 
         // level-1 tiles cover the whole instance space; a range pass keeps its share of every tile
-        const uint32_t ntiles1 = (uint32_t)((Ntot + kPartTile1 - 1) / kPartTile1);
+        const uint32_t ntiles1 = from_reads ? (uint32_t)((n_chunks + kRdThreads - 1) / kRdThreads)
+                                            : (uint32_t)((Ntot + kPartTileK - 1) / kPartTileK);
         ReadSrc S{};
         if (from_reads) {
             tile_read.alloc(((size_t)ntiles1 + 2) * sizeof(uint32_t));
             hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1 + 1 + 255) / 256), dim3(256), 0, ctx->stream,
-                               koff.as<uint64_t>(), rd->n, (uint64_t)ntiles1, kPartTileR, tile_read.as<uint32_t>());
+                               coff.as<uint64_t>(), rd->n, (uint64_t)ntiles1, (uint32_t)kRdThreads,
+                               tile_read.as<uint32_t>());
             check_launch("k_tile_reads");
-            S = ReadSrc{rd->d_words, rd->d_woff, rd->d_len, koff.as<uint64_t>(), tile_read.as<uint32_t>(), rd->n, (int)k};
+            S = ReadSrc{rd->d_words, rd->d_woff, rd->d_len, coff.as<uint64_t>(), tile_read.as<uint32_t>(), rd->n, n_chunks,
+                        (int)k};
         }
-        TileMap M1{nullptr, nullptr, 1, Ntot};
+        TileMap M1{nullptr, nullptr, 1, Ntot, 0, 1};
 
         // ---- level 1: histogram, offsets, scatter
         DevBuf hist1((size_t)nb1 * 4 + 16), cur1((size_t)nb1 * 4 + 16);
@@ -1192,9 +1349,9 @@ struct MsdRunner {
         if (nb1 > 1 || sel_bits) {
             const double hb = from_reads ? (double)rd->n_words * 8 : (double)N * rec;
             if (from_reads) {
-                launch_part<1, false, true>("part_hist1_reads", hb, ntiles1, nullptr, nullptr, S, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+                launch_part_reads<false, true>("part_hist1_reads", hb, ntiles1, S, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
             } else {
-                launch_part<0, false, true>("part_hist1_keys", hb, ntiles1, kin, nullptr, S, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+                launch_part<false, true>("part_hist1_keys", hb, ntiles1, kin, nullptr, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
             }
         } else {
             const uint32_t n32 = (uint32_t)N;
@@ -1234,11 +1391,11 @@ struct MsdRunner {
             const double pb = (from_reads ? (double)rd->n_words * 8 : (double)N * (rec + (has_val ? 4 : 0))) +
                               (double)N * (rec + (has_val ? 4 : 0));
             if (from_reads) {
-                if (has_val) launch_part<1, true, false>("part_scatter1_reads", pb, ntiles1, nullptr, nullptr, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
-                else launch_part<1, false, false>("part_scatter1_reads", pb, ntiles1, nullptr, nullptr, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
+                if (has_val) launch_part_reads<true, false>("part_scatter1_reads", pb, ntiles1, S, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
+                else launch_part_reads<false, false>("part_scatter1_reads", pb, ntiles1, S, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
             } else {
-                if (has_val) launch_part<0, true, false>("part_scatter1_keys", pb, ntiles1, kin, d_vals, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
-                else launch_part<0, false, false>("part_scatter1_keys", pb, ntiles1, kin, nullptr, S, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
+                if (has_val) launch_part<true, false>("part_scatter1_keys", pb, ntiles1, kin, d_vals, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
+                else launch_part<false, false>("part_scatter1_keys", pb, ntiles1, kin, nullptr, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
             }
         }
 
@@ -1251,11 +1408,11 @@ struct MsdRunner {
         BBK_HIP(hipMemcpyAsync(seg_bin.p, sbin.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), sel_bits, sel_val};
         const uint32_t ntiles2 = tstart[nb1];
-        TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), nb1, N};
+        TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), nb1, N, 0, 1};
         DevBuf hist2((size_t)nbuckets * 4 + 16), boff(((size_t)nbuckets + 1) * 4 + 16);
         BBK_HIP(hipMemsetAsync(hist2.p, 0, (size_t)nbuckets * 4 + 16, ctx->stream));
-        launch_part<0, false, true>("part_hist2", (double)N * rec, ntiles2, bufA.as<Key<W>>(), nullptr, S, M2, L2,
-                                    hist2.as<uint32_t>(), nullptr, nullptr, nullptr);
+        launch_part<false, true>("part_hist2", (double)N * rec, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2,
+                                 hist2.as<uint32_t>(), nullptr, nullptr, nullptr);
         {
             DevBuf h64(((size_t)nbuckets + 1) * 8);
             hipLaunchKernelGGL(k_u32_to_u64, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream,
@@ -1271,8 +1428,8 @@ struct MsdRunner {
         }
         {
             const double pb = 2.0 * (double)N * (rec + (has_val ? 4 : 0));
-            if (has_val) launch_part<0, true, false>("part_scatter2", pb, ntiles2, bufA.as<Key<W>>(), valA.as<uint32_t>(), S, M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), valB.as<uint32_t>());
-            else launch_part<0, false, false>("part_scatter2", pb, ntiles2, bufA.as<Key<W>>(), nullptr, S, M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), nullptr);
+            if (has_val) launch_part<true, false>("part_scatter2", pb, ntiles2, bufA.as<Key<W>>(), valA.as<uint32_t>(), M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), valB.as<uint32_t>());
+            else launch_part<false, false>("part_scatter2", pb, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), nullptr);
         }
         bufA.release();
         valA.release();

@@ -433,57 +433,74 @@ std::vector<PassDesc> key_passes(unsigned k) {
     return p;
 }
 
+// one stable counting pass src -> dst on the digit `pd` (hist/chunk: scratch of the caller)
 template <int W>
-static void sort_impl(bbk_ctx *ctx, Key<W> *keys, Key<W> *tmp, uint32_t *vals, uint32_t *vtmp, uint64_t n,
-                      const std::vector<PassDesc> &passes) {
-    if (n <= 1 || passes.empty()) return;
+static void sort_pass(bbk_ctx *ctx, const Key<W> *src, Key<W> *dst, const uint32_t *vsrc, uint32_t *vdst, uint64_t n,
+                      const PassDesc &pd, DevBuf &hist, DevBuf &chunk) {
+    constexpr int TILE = SortCfg<W>::TILE;
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    const uint64_t nchunks = (ntiles + kChunk - 1) / kChunk;
+    const bool hv = vsrc != nullptr;
+    const size_t dyn = sizeof(Key<W>) * TILE + (hv ? sizeof(uint32_t) * TILE : 0);
+    const double rec_bytes = (double)(sizeof(Key<W>) + (hv ? 4 : 0));
+    {
+        KernelTimer t(ctx, "hist", (double)n * sizeof(Key<W>));
+        hipLaunchKernelGGL(k_hist<W>, dim3((unsigned)ntiles), dim3(kThreads), 0, ctx->stream, src, n, pd,
+                           hist.as<uint32_t>());
+        check_launch("k_hist");
+    }
+    {
+        KernelTimer t(ctx, "scan", (double)ntiles * kRadix * 4 * 3);
+        hipLaunchKernelGGL(k_colsum, dim3((unsigned)nchunks), dim3(kRadix), 0, ctx->stream, hist.as<uint32_t>(), ntiles,
+                           chunk.as<uint64_t>());
+        hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kRadix), 0, ctx->stream, chunk.as<uint64_t>(), nchunks,
+                           (uint64_t *)nullptr);
+        hipLaunchKernelGGL(k_tile_offsets, dim3((unsigned)nchunks), dim3(kRadix), 0, ctx->stream, hist.as<uint32_t>(),
+                           ntiles, chunk.as<uint64_t>());
+        check_launch("scan kernels");
+    }
+    {
+        KernelTimer t(ctx, "scatter", 2.0 * (double)n * rec_bytes);
+        if (hv) {
+            hipLaunchKernelGGL((k_scatter<W, true>), dim3((unsigned)ntiles), dim3(kThreads), dyn, ctx->stream, src, dst,
+                               vsrc, vdst, n, pd, hist.as<uint32_t>());
+        } else {
+            hipLaunchKernelGGL((k_scatter<W, false>), dim3((unsigned)ntiles), dim3(kThreads), dyn, ctx->stream, src, dst,
+                               (const uint32_t *)nullptr, (uint32_t *)nullptr, n, pd, hist.as<uint32_t>());
+        }
+        check_launch("k_scatter");
+    }
+}
+
+template <int W>
+static void sort_scratch(uint64_t n, bool with_vals, DevBuf &hist, DevBuf &chunk) {
     BBK_REQUIRE(n < (1ull << 32), BBK_ERR_ARG, "sort_records: n=%llu does not fit 32-bit offsets (batch the input)",
                 (unsigned long long)n);
     constexpr int TILE = SortCfg<W>::TILE;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     const uint64_t nchunks = (ntiles + kChunk - 1) / kChunk;
-    DevBuf hist(ntiles * kRadix * sizeof(uint32_t));
-    DevBuf chunk(nchunks * kRadix * sizeof(uint64_t));
-    const size_t dyn = sizeof(Key<W>) * TILE + (vals ? sizeof(uint32_t) * TILE : 0);
-    if (vals) {
+    hist.alloc(ntiles * kRadix * sizeof(uint32_t));
+    chunk.alloc(nchunks * kRadix * sizeof(uint64_t));
+    const size_t dyn = sizeof(Key<W>) * TILE + (with_vals ? sizeof(uint32_t) * TILE : 0);
+    if (with_vals) {
         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter<W, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     } else {
         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scatter<W, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     }
+}
+
+template <int W>
+static void sort_impl(bbk_ctx *ctx, Key<W> *keys, Key<W> *tmp, uint32_t *vals, uint32_t *vtmp, uint64_t n,
+                      const std::vector<PassDesc> &passes) {
+    if (n <= 1 || passes.empty()) return;
+    DevBuf hist, chunk;
+    sort_scratch<W>(n, vals != nullptr, hist, chunk);
     Key<W> *src = keys, *dst = tmp;
     uint32_t *vsrc = vals, *vdst = vtmp;
-    const double rec_bytes = (double)(sizeof(Key<W>) + (vals ? 4 : 0));
     for (const PassDesc &pd : passes) {
-        {
-            KernelTimer t(ctx, "hist", (double)n * sizeof(Key<W>));
-            hipLaunchKernelGGL(k_hist<W>, dim3((unsigned)ntiles), dim3(kThreads), 0, ctx->stream, src, n, pd,
-                               hist.as<uint32_t>());
-            check_launch("k_hist");
-        }
-        {
-            KernelTimer t(ctx, "scan", (double)ntiles * kRadix * 4 * 3);
-            hipLaunchKernelGGL(k_colsum, dim3((unsigned)nchunks), dim3(kRadix), 0, ctx->stream, hist.as<uint32_t>(),
-                               ntiles, chunk.as<uint64_t>());
-            hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kRadix), 0, ctx->stream, chunk.as<uint64_t>(), nchunks,
-                               (uint64_t *)nullptr);
-            hipLaunchKernelGGL(k_tile_offsets, dim3((unsigned)nchunks), dim3(kRadix), 0, ctx->stream,
-                               hist.as<uint32_t>(), ntiles, chunk.as<uint64_t>());
-            check_launch("scan kernels");
-        }
-        {
-            KernelTimer t(ctx, "scatter", 2.0 * (double)n * rec_bytes);
-            if (vals) {
-                hipLaunchKernelGGL((k_scatter<W, true>), dim3((unsigned)ntiles), dim3(kThreads), dyn, ctx->stream, src,
-                                   dst, vsrc, vdst, n, pd, hist.as<uint32_t>());
-            } else {
-                hipLaunchKernelGGL((k_scatter<W, false>), dim3((unsigned)ntiles), dim3(kThreads), dyn, ctx->stream,
-                                   src, dst, (const uint32_t *)nullptr, (uint32_t *)nullptr, n, pd,
-                                   hist.as<uint32_t>());
-            }
-            check_launch("k_scatter");
-        }
+        sort_pass<W>(ctx, src, dst, vsrc, vdst, n, pd, hist, chunk);
         std::swap(src, dst);
         std::swap(vsrc, vdst);
     }
@@ -492,6 +509,28 @@ static void sort_impl(bbk_ctx *ctx, Key<W> *keys, Key<W> *tmp, uint32_t *vals, u
         if (vals) BBK_HIP(hipMemcpyAsync(vals, vsrc, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     }
     BBK_HIP(hipStreamSynchronize(ctx->stream));  // hist/chunk are freed on return
+}
+
+template <int W>
+static void partition_impl(bbk_ctx *ctx, const Key<W> *src, Key<W> *dst, const uint32_t *vsrc, uint32_t *vdst, uint64_t n,
+                           const PassDesc &pd) {
+    if (n == 0) return;
+    DevBuf hist, chunk;
+    sort_scratch<W>(n, vsrc != nullptr, hist, chunk);
+    sort_pass<W>(ctx, src, dst, vsrc, vdst, n, pd, hist, chunk);
+    BBK_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+// one stable pass src -> dst (both on the device, not aliased): records ordered by the digit, input order kept inside
+void partition_records(bbk_ctx *ctx, int W, const void *src, void *dst, const uint32_t *vsrc, uint32_t *vdst, uint64_t n,
+                       const PassDesc &pd) {
+    switch (W) {
+        case 1: partition_impl<1>(ctx, (const Key<1> *)src, (Key<1> *)dst, vsrc, vdst, n, pd); break;
+        case 2: partition_impl<2>(ctx, (const Key<2> *)src, (Key<2> *)dst, vsrc, vdst, n, pd); break;
+        case 3: partition_impl<3>(ctx, (const Key<3> *)src, (Key<3> *)dst, vsrc, vdst, n, pd); break;
+        case 4: partition_impl<4>(ctx, (const Key<4> *)src, (Key<4> *)dst, vsrc, vdst, n, pd); break;
+        default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %d", W);
+    }
 }
 
 void sort_records(bbk_ctx *ctx, int W, void *keys, void *keys_tmp, uint32_t *vals, uint32_t *vals_tmp, uint64_t n,

@@ -16,13 +16,13 @@ import json
 import re
 import sys
 
-FAMILY = [
-    (r"k_part<\d, 1, (true|false), false, true>", "part_scatter1_reads"),
-    (r"k_part<\d, 0, (true|false), false, true>", "part_scatter1_keys"),
-    (r"k_part<\d, 0, (true|false), false, false>", "part_scatter2"),
-    (r"k_part<\d, 1, (true|false), true, true>", "part_hist1_reads"),
-    (r"k_part<\d, 0, (true|false), true, true>", "part_hist1_keys"),
-    (r"k_part<\d, 0, (true|false), true, false>", "part_hist2"),
+FAMILY = [  # k_part_reads<W, HAS_VAL, HIST_ONLY>, k_part<W, HAS_VAL, HIST_ONLY, LVL1>
+    (r"k_part_reads<\d, (true|false), false>", "part_scatter1_reads"),
+    (r"k_part_reads<\d, (true|false), true>", "part_hist1_reads"),
+    (r"k_part<\d, (true|false), false, true>", "part_scatter1_keys"),
+    (r"k_part<\d, (true|false), false, false>", "part_scatter2"),
+    (r"k_part<\d, (true|false), true, true>", "part_hist1_keys"),
+    (r"k_part<\d, (true|false), true, false>", "part_hist2"),
     (r"k_bucket_hash", "lds_dedup"),
     (r"k_bucket<", "lds_sort"),
     (r"k_compact", "compact"),
