@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "bbk_internal.h"
@@ -150,29 +151,67 @@ struct TileMap {
     uint64_t n;
     uint32_t ntiles;  // tiles of the level
     uint32_t group;   // histogram kernels: consecutive tiles one workgroup walks
+    const uint4 *desc;  // level 2: per tile (first record, records, bins of its segment, flat index of bin 0),
+                        // precomputed so that a workgroup starts with one load instead of a binary search
 };
 
-__device__ inline void tile_range(const TileMap &M, uint32_t tile, uint32_t kPartTile, uint32_t *seg, uint64_t *begin,
-                                  uint32_t *count) {
-    if (!M.seg_tile_start) {
-        *seg = 0;
-        *begin = (uint64_t)tile * kPartTile;
-        const uint64_t rem = M.n - *begin;
-        *count = rem < (uint64_t)kPartTile ? (uint32_t)rem : (uint32_t)kPartTile;
-        return;
-    }
-    uint32_t lo = 0, hi = M.nseg;  // largest s with seg_tile_start[s] <= tile
+// level 2: tile -> descriptor (one thread per tile)
+__global__ void k_tile_desc(TileMap M, const uint32_t *__restrict__ seg_nb2, const uint32_t *__restrict__ seg_bin_start,
+                            uint32_t tile_size, uint4 *__restrict__ desc) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M.ntiles) return;
+    uint32_t lo = 0, hi = M.nseg;  // largest s with seg_tile_start[s] <= t
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (M.seg_tile_start[mid] <= tile) lo = mid;
+        if (M.seg_tile_start[mid] <= t) lo = mid;
         else hi = mid;
     }
-    *seg = lo;
-    const uint64_t b = (uint64_t)M.seg_off[lo] + (uint64_t)(tile - M.seg_tile_start[lo]) * kPartTile;
-    const uint64_t e = M.seg_off[lo + 1];
-    *begin = b;
-    *count = (e - b) < (uint64_t)kPartTile ? (uint32_t)(e - b) : (uint32_t)kPartTile;
+    const uint32_t b = M.seg_off[lo] + (t - M.seg_tile_start[lo]) * tile_size;
+    const uint32_t e = M.seg_off[lo + 1];
+    desc[t] = make_uint4(b, (e - b) < tile_size ? (e - b) : tile_size, seg_nb2[lo], seg_bin_start[lo]);
 }
+
+struct TileInfo {
+    uint64_t begin;
+    uint32_t count, nb;
+    uint64_t gbin0;
+};
+
+__device__ inline TileInfo tile_info(const TileMap &M, const PartLevel &L, uint32_t tile, uint32_t tile_size) {
+    TileInfo T;
+    if (M.desc) {
+        const uint4 d = M.desc[tile];
+        T.begin = d.x;
+        T.count = d.y;
+        T.nb = d.z;
+        T.gbin0 = d.w;
+    } else {  // level 1: one segment, tile t covers records [t * tile_size, ...)
+        T.begin = (uint64_t)tile * tile_size;
+        const uint64_t rem = M.n - T.begin;
+        T.count = rem < (uint64_t)tile_size ? (uint32_t)rem : tile_size;
+        T.nb = L.nb1;
+        T.gbin0 = 0;
+    }
+    return T;
+}
+
+#ifdef BBK_PHASE_PROF
+// phase clocks of the scatter kernels (diagnostic build only): [kernel kind][phase] summed shader cycles of
+// thread 0 of every workgroup, [..][7] = workgroups
+__device__ unsigned long long g_phase[4][8];
+#define BBK_PH(kind, ph, t_prev)                                                   \
+    do {                                                                           \
+        if (threadIdx.x == 0) {                                                    \
+            const unsigned long long t_now = clock64();                            \
+            atomicAdd(&g_phase[kind][ph], t_now - t_prev);                         \
+            t_prev = t_now;                                                        \
+        }                                                                          \
+    } while (0)
+#else
+#define BBK_PH(kind, ph, t_prev) \
+    do {                         \
+    } while (0)
+#endif
 
 // Common tail of the scatter kernels.  On entry lhist[b] = records of bin b in this tile and binrank[i] =
 // bin << 16 | rank-in-bin (0xFFFFFFFF: no record).  One global atomicAdd per non-empty bin reserves the
@@ -184,8 +223,11 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
                                           uint32_t *goff, uint32_t *scan_tmp, Key<W> *stage, uint32_t *vstage,
                                           uint32_t nb, uint64_t gbin0, const PartLevel &L,
                                           uint32_t *__restrict__ cursor, Key<W> *__restrict__ out,
-                                          uint32_t *__restrict__ vout) {
+                                          uint32_t *__restrict__ vout, int prof_kind = 0,
+                                          unsigned long long t_prev = 0) {
     const int tid = threadIdx.x;
+    (void)prof_kind;
+    (void)t_prev;
     uint32_t staged = 0;
     {
         constexpr int BPT = (MAXB + THREADS - 1) / THREADS;
@@ -224,6 +266,7 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
         }
     }
     __syncthreads();
+    BBK_PH(prof_kind, 2, t_prev);  // scan + global reservation
 
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -234,6 +277,7 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
         }
     }
     __syncthreads();
+    BBK_PH(prof_kind, 3, t_prev);  // reorder into LDS
 
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -248,6 +292,10 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
             if (HAS_VAL) vout[g] = vstage[pos];
         }
     }
+    BBK_PH(prof_kind, 4, t_prev);  // store issue
+#ifdef BBK_PHASE_PROF
+    if (threadIdx.x == 0) atomicAdd(&g_phase[prof_kind][7], 1ull);
+#endif
 }
 
 // One partition level over a key array.  HIST_ONLY: accumulate the level histogram; else scatter.
@@ -276,31 +324,37 @@ __global__ __launch_bounds__(PartCfg<W>::THREADS) void k_part(const Key<W> *__re
         // level-1 segment changes and at the end: one global atomic per (workgroup, bin), not per (tile, bin)
         const uint32_t t0 = blockIdx.x * M.group;
         const uint32_t t1 = t0 + M.group < M.ntiles ? t0 + M.group : M.ntiles;
-        uint32_t cur = 0xFFFFFFFFu, nb = 0;
-        uint64_t gbin0 = 0;
+        uint32_t nb = 0;
+        uint64_t gbin0 = ~0ull;  // doubles as the identity of the current segment
         for (uint32_t t = t0; t < t1; ++t) {
-            uint32_t seg, count;
-            uint64_t begin;
-            tile_range(M, t, (uint32_t)kPartTile, &seg, &begin, &count);
-            if (seg != cur) {
+            const TileInfo T = tile_info(M, L, t, (uint32_t)kPartTile);
+            const uint64_t begin = T.begin;
+            const uint32_t count = T.count;
+            if (T.gbin0 != gbin0) {
                 __syncthreads();
                 for (uint32_t b = tid; b < nb; b += kPartThreads) {
                     const uint32_t c = lhist[b];
                     if (c) atomicAdd(&ghist[gbin0 + b], c);
                 }
                 __syncthreads();
-                cur = seg;
-                nb = (L.level == 1) ? L.nb1 : L.seg_nb2[seg];
-                gbin0 = (L.level == 1) ? 0ull : (uint64_t)L.seg_bin_start[seg];
+                nb = T.nb;
+                gbin0 = T.gbin0;
                 for (uint32_t b = tid; b < nb; b += kPartThreads) lhist[b] = 0;
                 __syncthreads();
+            }
+            // all loads first (unconditional, index clamped into the tile), then the ranking: a load inside the
+            // `local < count` branch would be waited for before the next one is issued
+            Key<W> keys[kPartItems];
+#pragma unroll
+            for (int i = 0; i < kPartItems; ++i) {
+                const uint32_t local = (uint32_t)(i * kPartThreads + tid);
+                keys[i] = key_load<W>(&in[begin + (local < count ? local : count - 1u)]);
             }
 #pragma unroll
             for (int i = 0; i < kPartItems; ++i) {
                 const uint32_t local = (uint32_t)(i * kPartThreads + tid);
                 if (local < count) {
-                    const Key<W> key = key_load<W>(&in[begin + local]);
-                    uint32_t pfx = prefix_of<W>(key, L.dmode, L.w0bits);
+                    uint32_t pfx = prefix_of<W>(keys[i], L.dmode, L.w0bits);
                     if (select_prefix(pfx, L)) atomicAdd(&lhist[bin_of(pfx, L, nb)], 1u);
                 }
             }
@@ -312,29 +366,39 @@ __global__ __launch_bounds__(PartCfg<W>::THREADS) void k_part(const Key<W> *__re
         }
         return;
     }
-    uint32_t seg, count;
-    uint64_t begin;
-    tile_range(M, blockIdx.x, (uint32_t)kPartTile, &seg, &begin, &count);
-    const uint32_t nb = (L.level == 1) ? L.nb1 : L.seg_nb2[seg];
-    const uint64_t gbin0 = (L.level == 1) ? 0ull : (uint64_t)L.seg_bin_start[seg];  // flat index of bin 0
+#ifdef BBK_PHASE_PROF
+    unsigned long long t_prev = clock64();
+    const int prof_kind = LVL1 ? 1 : 2;
+#else
+    const unsigned long long t_prev = 0;
+    const int prof_kind = 0;
+#endif
+    const TileInfo T = tile_info(M, L, blockIdx.x, (uint32_t)kPartTile);
+    const uint64_t begin = T.begin, gbin0 = T.gbin0;  // gbin0: flat index of bin 0 in the cursor array
+    const uint32_t count = T.count, nb = T.nb;
 
     for (uint32_t b = tid; b < nb; b += kPartThreads) lhist[b] = 0;
     __syncthreads();
+    BBK_PH(prof_kind, 0, t_prev);  // tile lookup
 
     Key<W> keys[kPartItems];
     uint32_t vals[kPartItems];
     uint32_t binrank[kPartItems];  // bin << 16 | rank (rank < 8192 fits 13 bits; bins < 1024)
-    // striped over the block: coalesced 8/16-byte loads
+    // striped over the block: coalesced 8/16-byte loads.  All loads are issued first (unconditional, index
+    // clamped into the tile): a load inside the `local < count` branch would be waited for before the next
+    // one is issued, i.e. one full memory latency per record.
 #pragma unroll
     for (int i = 0; i < kPartItems; ++i) {
         const uint32_t local = (uint32_t)(i * kPartThreads + tid);
+        const uint64_t at = begin + (local < count ? local : count - 1u);
+        keys[i] = key_load<W>(&in[at]);
+        vals[i] = HAS_VAL ? vin[at] : 0u;
+    }
 #pragma unroll
-        for (int w = 0; w < W; ++w) keys[i].w[w] = 0;
-        vals[i] = 0;
+    for (int i = 0; i < kPartItems; ++i) {
+        const uint32_t local = (uint32_t)(i * kPartThreads + tid);
         binrank[i] = 0xFFFFFFFFu;
         if (local < count) {
-            keys[i] = key_load<W>(&in[begin + local]);
-            if (HAS_VAL) vals[i] = vin[begin + local];
             uint32_t pfx = prefix_of<W>(keys[i], L.dmode, L.w0bits);
             if (select_prefix(pfx, L)) {
                 const uint32_t b = bin_of(pfx, L, nb);
@@ -344,8 +408,9 @@ __global__ __launch_bounds__(PartCfg<W>::THREADS) void k_part(const Key<W> *__re
         }
     }
     __syncthreads();
+    BBK_PH(prof_kind, 1, t_prev);  // load + LDS ranking
     part_tail<W, kPartItems, kPartThreads, MAXB, HAS_VAL>(keys, vals, binrank, lhist, lstart, goff, scan_tmp, stage, vstage,
-                                                        nb, gbin0, L, cursor, out, vout);
+                                                        nb, gbin0, L, cursor, out, vout, prof_kind, t_prev);
 }
 
 static size_t part_smem(int W, int tile, bool has_val, bool hist_only, bool lvl1) {
@@ -476,6 +541,11 @@ __global__ __launch_bounds__(kRdThreads) void k_part_reads(ReadSrc S, PartLevel 
     const uint32_t nb = L.nb1;
     const uint32_t ntiles = (uint32_t)((S.n_chunks + kRdThreads - 1) / kRdThreads);
     for (uint32_t b = tid; b < nb; b += kRdThreads) lhist[b] = 0;
+#ifdef BBK_PHASE_PROF
+    unsigned long long t_prev = clock64();
+#else
+    const unsigned long long t_prev = 0;
+#endif
 
     // scatter: one tile per workgroup (grid == tiles).  Histogram: a workgroup walks many tiles and adds
     // its LDS histogram to the global one once (512 atomics per workgroup instead of per tile).
@@ -518,6 +588,7 @@ __global__ __launch_bounds__(kRdThreads) void k_part_reads(ReadSrc S, PartLevel 
     } else {
         __syncthreads();
     }
+    if (!HIST_ONLY) BBK_PH(0, 0, t_prev);  // read tables + words into LDS
 
     Key<W> keys[CH];
     uint32_t vals[CH];
@@ -554,8 +625,9 @@ __global__ __launch_bounds__(kRdThreads) void k_part_reads(ReadSrc S, PartLevel 
     __syncthreads();  // histogram complete / the read tables may be overwritten
 
     if constexpr (!HIST_ONLY) {
+        BBK_PH(0, 1, t_prev);  // extraction + LDS ranking
         part_tail<W, CH, kRdThreads, MAXB, HAS_VAL>(keys, vals, binrank, lhist, lstart, goff, scan_tmp, stage, vstage, nb,
-                                                    0ull, L, cursor, out, vout);
+                                                    0ull, L, cursor, out, vout, 0, t_prev);
         return;
     }
     }
@@ -622,12 +694,25 @@ __global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_
         if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
         return;
     }
+    {
+        // all loads first (unconditional, index clamped into the bucket), then the LDS stores: a load inside the
+        // `p < n` branch is waited for before the next one is issued -- one memory latency per record
+        Key<W> rk[ITEMS];
+        uint32_t rv[ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t p = (uint32_t)(i * NT + tid);
-        if (p < n) {
-            key_store<W>(&skeys[p], key_load<W>(&buf[start + p]));
-            if (IN_VAL) svals[p] = vals[start + p];
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t p = (uint32_t)(i * NT + tid);
+            const uint32_t at = start + (p < n ? p : n - 1u);
+            rk[i] = key_load<W>(&buf[at]);
+            rv[i] = IN_VAL ? vals[at] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t p = (uint32_t)(i * NT + tid);
+            if (p < n) {
+                key_store<W>(&skeys[p], rk[i]);
+                if (IN_VAL) svals[p] = rv[i];
+            }
         }
     }
     __syncthreads();
@@ -999,13 +1084,21 @@ __global__ __launch_bounds__(kHashIdxThreads) void k_bucket_hashidx(Key<W> *__re
         if (OP != 0) pay[s] = 0;
     }
     uint32_t vv[kHashIdxItems];
+    {
+        // loads first, unconditional (see k_bucket)
+        Key<W> rk[kHashIdxItems];
 #pragma unroll
-    for (int i = 0; i < kHashIdxItems; ++i) {
-        const uint32_t p = (uint32_t)(i * kHashIdxThreads + tid);
-        vv[i] = 0;
-        if (p < n) {
-            key_store<W>(&skeys[p], key_load<W>(&buf[start + p]));
-            if (IN_VAL) vv[i] = vals[start + p];
+        for (int i = 0; i < kHashIdxItems; ++i) {
+            const uint32_t p = (uint32_t)(i * kHashIdxThreads + tid);
+            const uint32_t at = start + (p < n ? p : n - 1u);
+            rk[i] = key_load<W>(&buf[at]);
+            vv[i] = IN_VAL ? vals[at] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < kHashIdxItems; ++i) {
+            const uint32_t p = (uint32_t)(i * kHashIdxThreads + tid);
+            if (p < n) key_store<W>(&skeys[p], rk[i]);
+            else vv[i] = 0;
         }
     }
     __syncthreads();
@@ -1340,7 +1433,7 @@ struct MsdRunner {
             S = ReadSrc{rd->d_words, rd->d_woff, rd->d_len, coff.as<uint64_t>(), tile_read.as<uint32_t>(), rd->n, n_chunks,
                         (int)k};
         }
-        TileMap M1{nullptr, nullptr, 1, Ntot, 0, 1};
+        TileMap M1{nullptr, nullptr, 1, Ntot, 0, 1, nullptr};
 
         // ---- level 1: histogram, offsets, scatter
         DevBuf hist1((size_t)nb1 * 4 + 16), cur1((size_t)nb1 * 4 + 16);
@@ -1408,7 +1501,14 @@ struct MsdRunner {
         BBK_HIP(hipMemcpyAsync(seg_bin.p, sbin.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), sel_bits, sel_val};
         const uint32_t ntiles2 = tstart[nb1];
-        TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), nb1, N, 0, 1};
+        TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), nb1, N, ntiles2, 1, nullptr};
+        DevBuf desc2((size_t)ntiles2 * sizeof(uint4) + 16);
+        if (ntiles2) {
+            hipLaunchKernelGGL(k_tile_desc, dim3((ntiles2 + 255) / 256), dim3(256), 0, ctx->stream, M2, seg_nb2.as<uint32_t>(),
+                               seg_bin.as<uint32_t>(), kPartTileK, desc2.as<uint4>());
+            check_launch("k_tile_desc");
+        }
+        M2.desc = desc2.as<uint4>();
         DevBuf hist2((size_t)nbuckets * 4 + 16), boff(((size_t)nbuckets + 1) * 4 + 16);
         BBK_HIP(hipMemsetAsync(hist2.p, 0, (size_t)nbuckets * 4 + 16, ctx->stream));
         launch_part<false, true>("part_hist2", (double)N * rec, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2,
@@ -1580,9 +1680,30 @@ struct MsdRunner {
     }
 };
 
+#ifdef BBK_PHASE_PROF
+static void dump_phases() {
+    unsigned long long h[4][8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) != hipSuccess) return;
+    static const char *kinds[4] = {"scatter1_reads", "scatter1_keys", "scatter2", "-"};
+    for (int q = 0; q < 3; ++q) {
+        if (!h[q][7]) continue;
+        fprintf(stderr, "[bbk phase] %-15s wgs=%llu cycles/wg:", kinds[q], h[q][7]);
+        for (int p = 0; p < 5; ++p) fprintf(stderr, " p%d=%.0f", p, (double)h[q][p] / (double)h[q][7]);
+        fprintf(stderr, "\n");
+    }
+    memset(h, 0, sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof(h));
+}
+#endif
+
 bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_reads *rd, const void *d_keys,
                      const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out) {
     const int W = (int)words_of(k);
+#ifdef BBK_PHASE_PROF
+    struct Dump {
+        ~Dump() { dump_phases(); }
+    } dump_on_exit;
+#endif
     if (W == 1) {
         MsdRunner<1> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
         return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
