@@ -1004,9 +1004,13 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
 #pragma unroll
     for (int i = 0; i < kHashItems; ++i) {
         if (kk[i] != EMPTY) {
-            uint64_t h = kk[i] * 0x9E3779B97F4A7C15ull;
-            h ^= h >> 29;
-            uint32_t slot = (uint32_t)(h * 0xBF58476D1CE4E5B9ull >> 40) & (kHashSlots - 1);
+            // 32-bit mix with multipliers of its own (the partition levels consumed the top bits of part_hash32)
+            uint32_t h = ((uint32_t)kk[i] ^ 0x7F4A7C15u) * 0x2C1B3C6Du;
+            h ^= h >> 15;
+            h += (uint32_t)(kk[i] >> 32) * 0x297A2D39u;
+            h ^= h >> 14;
+            h *= 0x9E3779B1u;
+            uint32_t slot = (h >> 19) & (kHashSlots - 1);
             for (;;) {
                 const unsigned long long old = atomicCAS(&tab[slot], EMPTY, (unsigned long long)kk[i]);
                 if (old == EMPTY || old == kk[i]) break;
@@ -1018,11 +1022,12 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
         }
     }
     __syncthreads();
-    // compaction of the occupied slots: thread t owns slots [t*16, t*16+16)
+    // compaction of the occupied slots: thread t owns slots t, t + 512, ... (consecutive lanes read
+    // consecutive 8-byte slots: no LDS bank conflicts; the output order is free, the set is unsorted)
     constexpr int SPT = kHashSlots / kHashThreads;
     uint32_t cnt = 0;
 #pragma unroll
-    for (int j = 0; j < SPT; ++j) cnt += tab[tid * SPT + j] != EMPTY ? 1u : 0u;
+    for (int j = 0; j < SPT; ++j) cnt += tab[j * kHashThreads + tid] != EMPTY ? 1u : 0u;
     uint32_t incl = cnt;
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) {
@@ -1039,10 +1044,10 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
     uint32_t o = start + wbase + incl - cnt;
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
-        const unsigned long long key = tab[tid * SPT + j];
+        const unsigned long long key = tab[j * kHashThreads + tid];
         if (key != EMPTY) {
             buf[o].w[0] = key;
-            if (OP != 0) vals[o] = pay[tid * SPT + j];
+            if (OP != 0) vals[o] = pay[j * kHashThreads + tid];
             ++o;
         }
     }
@@ -1124,7 +1129,7 @@ __global__ __launch_bounds__(kHashIdxThreads) void k_bucket_hashidx(Key<W> *__re
     constexpr int SPT = kHashIdxSlots / kHashIdxThreads;
     uint32_t cnt = 0;
 #pragma unroll
-    for (int j = 0; j < SPT; ++j) cnt += tab[tid * SPT + j] != EMPTY ? 1u : 0u;
+    for (int j = 0; j < SPT; ++j) cnt += tab[j * kHashIdxThreads + tid] != EMPTY ? 1u : 0u;  // no bank conflicts
     uint32_t incl = cnt;
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) {
@@ -1141,10 +1146,10 @@ __global__ __launch_bounds__(kHashIdxThreads) void k_bucket_hashidx(Key<W> *__re
     uint32_t o = start + wbase + incl - cnt;
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
-        const uint32_t idx = tab[tid * SPT + j];
+        const uint32_t idx = tab[j * kHashIdxThreads + tid];
         if (idx != EMPTY) {
             key_store<W>(&buf[o], key_load<W>(&skeys[idx]));
-            if (OP != 0) vals[o] = pay[tid * SPT + j];
+            if (OP != 0) vals[o] = pay[j * kHashIdxThreads + tid];
             ++o;
         }
     }
