@@ -669,6 +669,98 @@ struct BucketArgs {
 };
 
 // OP: 0 unique only, 1 COUNT (run length), 2 SUM of vals, 3 OR of vals.  NT threads, CAP = NT * ITEMS.
+// Heads + segmented reduce of a bucket that lies sorted in LDS (skeys[0, n), svals alongside when the records
+// carry a payload); the distinct records are written back in place at buf[start ...], their reduced payloads
+// to vals, the count to dcount[b].  Blocked ownership: thread t owns [t*ITEMS, (t+1)*ITEMS).
+template <int W, int NT, int ITEMS, int OP>
+__device__ __forceinline__ void bucket_reduce(Key<W> *skeys, uint32_t *svals, uint32_t *scan_tmp, uint32_t n, uint32_t start,
+                                              uint32_t b, Key<W> *__restrict__ buf, uint32_t *__restrict__ vals,
+                                              const BucketArgs &A) {
+    constexpr int NWAVES = NT / 64;
+    constexpr bool IN_VAL = OP >= 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Key<W> mine[ITEMS];
+    uint32_t mv[ITEMS];
+    const uint32_t p0 = (uint32_t)tid * ITEMS;
+    Key<W> prev;
+#pragma unroll
+    for (int j = 0; j < W; ++j) prev.w[j] = ~0ull;  // cannot equal a real key: unused high bits are 0
+    if (p0 > 0 && p0 - 1 < n) prev = key_load<W>(&skeys[p0 - 1]);
+    uint32_t nheads = 0;
+    uint32_t headbits = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) mine[i].w[j] = 0;
+        mv[i] = 0;
+        if (p0 + i < n) {
+            mine[i] = key_load<W>(&skeys[p0 + i]);
+            if (IN_VAL) mv[i] = svals[p0 + i];
+            const bool h = (i == 0) ? !key_eq<W>(mine[0], prev) : !key_eq<W>(mine[i], mine[i - 1]);
+            if (h) {
+                headbits |= 1u << i;
+                ++nheads;
+            }
+        }
+    }
+    uint32_t excl, total;
+    {
+        uint32_t incl = nheads;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            uint32_t t = __shfl_up(incl, dd, 64);
+            if (lane >= dd) incl += t;
+        }
+        __syncthreads();  // everyone has its keys in registers: skeys may be reused below
+        if (lane == 63) scan_tmp[wave] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+        for (int j = 0; j < NWAVES; ++j) {
+            if (j < wave) wbase += scan_tmp[j];
+            tot += scan_tmp[j];
+        }
+        excl = wbase + incl - nheads;
+        total = tot;
+    }
+    uint32_t *acc = reinterpret_cast<uint32_t *>(skeys);  // CAP u32 fit in the key buffer
+    if (OP != 0) {
+        for (uint32_t s = tid; s < total; s += NT) acc[s] = 0;
+        __syncthreads();
+    }
+    {
+        int seg = (int)excl - 1;  // segment of the records before my first head
+        uint32_t a = 0;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            if (p0 + i < n) {
+                if (headbits & (1u << i)) {
+                    if (OP != 0 && any) {
+                        if (OP == 3) atomicOr(&acc[seg], a);
+                        else atomicAdd(&acc[seg], a);
+                    }
+                    ++seg;
+                    a = 0;
+                    key_store<W>(&buf[start + (uint32_t)seg], mine[i]);  // distinct keys, in place
+                }
+                any = true;
+                if (OP == 1) a += 1;
+                else if (OP == 2) a += mv[i];
+                else if (OP == 3) a |= mv[i];
+            }
+        }
+        if (OP != 0 && any) {
+            if (OP == 3) atomicOr(&acc[seg], a);
+            else atomicAdd(&acc[seg], a);
+        }
+    }
+    if (OP != 0) {
+        __syncthreads();
+        for (uint32_t s = tid; s < total; s += NT) vals[start + s] = acc[s];
+    }
+    if (tid == 0) A.dcount[b] = total;
+}
+
 template <int W, int NT, int ITEMS, int OP>
 __global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_t *__restrict__ vals, BucketArgs A) {
     constexpr int CAP = NT * ITEMS;
@@ -865,87 +957,182 @@ __global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_
         }
     }
 
-    // ---- heads + segmented reduce; blocked ownership: thread t owns [t*ITEMS, (t+1)*ITEMS)
-    Key<W> mine[ITEMS];
-    uint32_t mv[ITEMS];
-    const uint32_t p0 = (uint32_t)tid * ITEMS;
-    Key<W> prev;
-#pragma unroll
-    for (int j = 0; j < W; ++j) prev.w[j] = ~0ull;  // cannot equal a real key: unused high bits are 0
-    if (p0 > 0 && p0 - 1 < n) prev = key_load<W>(&skeys[p0 - 1]);
-    uint32_t nheads = 0;
-    uint32_t headbits = 0;
+    bucket_reduce<W, NT, ITEMS, OP>(skeys, svals, scan_tmp, n, start, b, buf, vals, A);
+}
+
+// ---- first-choice bucket kernel: ONE distribution pass instead of ballot-ranked radix passes.
+// The records of a bucket are spread evenly over its key range (KEYS/REF mode: a contiguous range of k-mers
+// of a genome), so kDistBins bins over the top bits of (word 0 - bucket minimum) hold about one record
+// each: count with LDS atomics, scan, scatter with returning atomics (the order inside a bin is arbitrary),
+// then the owner of a bin puts it in order by insertion on the whole key.  A bin above kDistMaxBin (skewed
+// keys, a k-mer repeated hundreds of times in an unreduced stream) marks the bucket as overflowing and the
+// host hands it to k_bucket, which takes any distribution.
+constexpr int kDistBins = 4096;
+constexpr uint32_t kDistMaxBin = 96;  // equal keys insert in linear time; only distinct keys cost n^2
+
+template <int W, int NT, int ITEMS, int OP>
+__global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, uint32_t *__restrict__ vals, BucketArgs A) {
+    constexpr int CAP = NT * ITEMS;
+    constexpr int NWAVES = NT / 64;
+    constexpr int BPT = kDistBins / NT;
+    constexpr bool IN_VAL = OP >= 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: bins[kDistBins] | scan[32] | mm[2 * NWAVES] (u64) | skeys[CAP] | svals[CAP] (IN_VAL)
+    uint32_t *bins = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *scan_tmp = bins + kDistBins;
+    uint64_t *mm = reinterpret_cast<uint64_t *>(scan_tmp + 32);
+    Key<W> *skeys = reinterpret_cast<Key<W> *>(mm + 2 * NWAVES);
+    uint32_t *svals = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(skeys) + sizeof(Key<W>) * CAP);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = A.bucket_ids ? A.bucket_ids[blockIdx.x] : blockIdx.x;
+    const uint32_t start = A.boff[b];
+    const uint32_t n = A.boff[b + 1] - start;
+    if (n == 0) {
+        if (tid == 0) A.dcount[b] = 0;
+        return;
+    }
+    if (n > (uint32_t)CAP) {
+        if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
+        return;
+    }
+    for (uint32_t q = tid; q < (uint32_t)kDistBins; q += NT) bins[q] = 0;
+
+    // records of this thread (striped over the bucket); all loads issued before the first use
+    Key<W> keys[ITEMS];
+    uint32_t v[IN_VAL ? ITEMS : 1];
+    uint64_t mn = ~0ull, mx = 0;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-#pragma unroll
-        for (int j = 0; j < W; ++j) mine[i].w[j] = 0;
-        mv[i] = 0;
-        if (p0 + i < n) {
-            mine[i] = key_load<W>(&skeys[p0 + i]);
-            if (IN_VAL) mv[i] = svals[p0 + i];
-            const bool h = (i == 0) ? !key_eq<W>(mine[0], prev) : !key_eq<W>(mine[i], mine[i - 1]);
-            if (h) {
-                headbits |= 1u << i;
-                ++nheads;
-            }
-        }
+        const uint32_t p = (uint32_t)(i * NT + tid);
+        const uint32_t at = start + (p < n ? p : n - 1u);
+        keys[i] = key_load<W>(&buf[at]);
+        if (IN_VAL) v[i] = vals[at];
     }
-    uint32_t excl, total;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {  // clamped duplicates do not change min / max
+        const uint64_t x = keys[i].w[0];
+        mn = x < mn ? x : mn;
+        mx = x > mx ? x : mx;
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+        const uint64_t a = __shfl_xor(mn, dd, 64), c = __shfl_xor(mx, dd, 64);
+        mn = a < mn ? a : mn;
+        mx = c > mx ? c : mx;
+    }
+    if (lane == 0) {
+        mm[2 * wave] = mn;
+        mm[2 * wave + 1] = mx;
+    }
+    __syncthreads();  // bins zeroed, min / max of every wave visible
+    mn = ~0ull;
+    mx = 0;
+#pragma unroll
+    for (int j = 0; j < NWAVES; ++j) {
+        mn = mm[2 * j] < mn ? mm[2 * j] : mn;
+        mx = mm[2 * j + 1] > mx ? mm[2 * j + 1] : mx;
+    }
+    const uint64_t kmin = mn;
+    const int rbits = 64 - __builtin_clzll((mx - mn) | 1ull);
+    const int sh = rbits > 12 ? rbits - 12 : 0;  // digit = (word 0 - min) >> sh < 4096
+
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t p = (uint32_t)(i * NT + tid);
+        if (p < n) atomicAdd(&bins[(uint32_t)((keys[i].w[0] - kmin) >> sh)], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the bins; thread t owns bins [t*BPT, (t+1)*BPT)
+    uint32_t c[BPT];
+    uint32_t sum = 0;
+    bool big = false;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+        c[q] = bins[tid * BPT + q];
+        sum += c[q];
+        big = big || c[q] > kDistMaxBin;
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        uint32_t t = __shfl_up(incl, dd, 64);
+        if (lane >= dd) incl += t;
+    }
+    if (lane == 63) scan_tmp[wave] = incl;
+    if (__syncthreads_or(big)) {  // nothing has been written: the second-chance kernel takes the bucket
+        if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
+        return;
+    }
+    uint32_t first = incl - sum;
+    for (int j = 0; j < wave; ++j) first += scan_tmp[j];
     {
-        uint32_t incl = nheads;
+        uint32_t ex = first;
 #pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            uint32_t t = __shfl_up(incl, dd, 64);
-            if (lane >= dd) incl += t;
+        for (int q = 0; q < BPT; ++q) {
+            bins[tid * BPT + q] = ex;
+            ex += c[q];
         }
-        __syncthreads();  // everyone has its keys in registers: skeys may be reused below
-        if (lane == 63) scan_tmp[wave] = incl;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-        for (int j = 0; j < NWAVES; ++j) {
-            if (j < wave) wbase += scan_tmp[j];
-            tot += scan_tmp[j];
-        }
-        excl = wbase + incl - nheads;
-        total = tot;
     }
-    uint32_t *acc = reinterpret_cast<uint32_t *>(skeys);  // CAP u32 fit in the key buffer
-    if (OP != 0) {
-        for (uint32_t s = tid; s < total; s += NT) acc[s] = 0;
-        __syncthreads();
-    }
-    {
-        int seg = (int)excl - 1;  // segment of the records before my first head
-        uint32_t a = 0;
-        bool any = false;
+    __syncthreads();
+    uint32_t pos_of[ITEMS];  // where the scatter put the record (breaks ties between equal keys)
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            if (p0 + i < n) {
-                if (headbits & (1u << i)) {
-                    if (OP != 0 && any) {
-                        if (OP == 3) atomicOr(&acc[seg], a);
-                        else atomicAdd(&acc[seg], a);
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t p = (uint32_t)(i * NT + tid);
+        pos_of[i] = 0;
+        if (p < n) {
+            const uint32_t pos = atomicAdd(&bins[(uint32_t)((keys[i].w[0] - kmin) >> sh)], 1u);
+            key_store<W>(&skeys[pos], keys[i]);
+            pos_of[i] = pos;
+        }
+    }
+    __syncthreads();
+    // order inside the bins, record-parallel: a record's final place is its bin's start plus the number of
+    // records of the bin that go before it (smaller key; equal key: scattered to a lower position).  After the
+    // scatter bins[d] is the END of bin d, so bin d = [bins[d-1], bins[d]).
+    uint32_t dest[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t p = (uint32_t)(i * NT + tid);
+        dest[i] = 0xFFFFFFFFu;
+        if (p < n) {
+            const uint32_t d = (uint32_t)((keys[i].w[0] - kmin) >> sh);
+            const uint32_t sb = d ? bins[d - 1] : 0u, e = bins[d];
+            uint32_t before = 0;
+            if (e - sb > 1) {
+                for (uint32_t y = sb; y < e; y += 4) {  // four candidates in flight per round
+                    Key<W> o[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) o[u] = key_load<W>(&skeys[y + u < e ? y + u : e - 1]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (y + u < e) {
+                            const bool lt = key_less_words<W>(o[u], keys[i]);
+                            const bool eq = key_eq<W>(o[u], keys[i]);
+                            before += (lt || (eq && y + u < pos_of[i])) ? 1u : 0u;
+                        }
                     }
-                    ++seg;
-                    a = 0;
-                    key_store<W>(&buf[start + (uint32_t)seg], mine[i]);  // distinct keys, in place
                 }
-                any = true;
-                if (OP == 1) a += 1;
-                else if (OP == 2) a += mv[i];
-                else if (OP == 3) a |= mv[i];
             }
-        }
-        if (OP != 0 && any) {
-            if (OP == 3) atomicOr(&acc[seg], a);
-            else atomicAdd(&acc[seg], a);
+            dest[i] = sb + before;
         }
     }
-    if (OP != 0) {
-        __syncthreads();
-        for (uint32_t s = tid; s < total; s += NT) vals[start + s] = acc[s];
+    __syncthreads();  // every rank is computed from the scattered order: only now overwrite it
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        if (dest[i] != 0xFFFFFFFFu) {
+            key_store<W>(&skeys[dest[i]], keys[i]);
+            if (IN_VAL) svals[dest[i]] = v[i];
+        }
     }
-    if (tid == 0) A.dcount[b] = total;
+    __syncthreads();
+    bucket_reduce<W, NT, ITEMS, OP>(skeys, svals, scan_tmp, n, start, b, buf, vals, A);
+}
+
+template <int W, int NT, int ITEMS, int OP>
+static size_t bucket_dist_smem() {
+    return sizeof(uint32_t) * (kDistBins + 32) + sizeof(uint64_t) * 2 * (NT / 64) + (size_t)W * 8 * NT * ITEMS +
+           (OP >= 2 ? 4 * NT * ITEMS : 0);
 }
 
 template <int W, int NT, int ITEMS, int OP>
@@ -1218,8 +1405,12 @@ __global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, uint64_t n, 
 // are spread over 512 threads x 11 to keep 8 waves on the CU.
 template <int W>
 struct BktCfg {
-    static constexpr int NT = (W == 1) ? 256 : 512;
-    static constexpr int ITEMS = (W == 1) ? 23 : 11;
+#ifndef BBK_BKT_NT
+#define BBK_BKT_NT 256
+#define BBK_BKT_ITEMS 23
+#endif
+    static constexpr int NT = (W == 1) ? BBK_BKT_NT : 512;
+    static constexpr int ITEMS = (W == 1) ? BBK_BKT_ITEMS : 11;
     static constexpr uint32_t CAP = NT * ITEMS;
     static constexpr int NT2 = 512;                               // second-chance kernel
     static constexpr int ITEMS2 = (W == 1) ? 23 : 11;
@@ -1277,12 +1468,17 @@ struct MsdRunner {
         check_launch(fam);
     }
 
-    template <int NT, int OP>
+    // first pass: the one-pass distribution sort; second chance (SECOND): ballot-ranked radix passes, which
+    // take any key distribution and twice the records
+    template <bool SECOND, int OP>
     void launch_bucket(uint32_t nblocks, Key<W> *buf, uint32_t *vals, BucketArgs A, double bytes) {
         if (nblocks == 0) return;
-        constexpr int IT = (NT == BktCfg<W>::NT) ? BktCfg<W>::ITEMS : BktCfg<W>::ITEMS2;
-        const size_t sm = bucket_smem<W, NT, IT, OP>();
-        auto fn = k_bucket<W, NT, IT, OP>;
+        constexpr int NT = SECOND ? BktCfg<W>::NT2 : BktCfg<W>::NT;
+        constexpr int IT = SECOND ? BktCfg<W>::ITEMS2 : BktCfg<W>::ITEMS;
+        static const bool no_dist = getenv("BBK_NO_DIST") != nullptr;  // A/B switch
+        const bool dist = !SECOND && !no_dist;
+        const size_t sm = dist ? bucket_dist_smem<W, NT, IT, OP>() : bucket_smem<W, NT, IT, OP>();
+        auto fn = dist ? k_bucket_dist<W, NT, IT, OP> : k_bucket<W, NT, IT, OP>;
         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)sm));
         KernelTimer t(ctx, "lds_sort", bytes);
@@ -1324,7 +1520,7 @@ struct MsdRunner {
         }
     }
 
-    template <int NT>
+    template <bool SECOND>
     void bucket_dispatch(uint32_t nblocks, Key<W> *buf, uint32_t *vals, BucketArgs A, double bytes,
                          bool allow_hash = true) {
         if (allow_hash && use_hashidx_dedup()) {
@@ -1346,10 +1542,10 @@ struct MsdRunner {
             }
         }
         switch (op) {
-            case MSD_OP_NONE: launch_bucket<NT, 0>(nblocks, buf, vals, A, bytes); break;
-            case MSD_OP_COUNT: launch_bucket<NT, 1>(nblocks, buf, vals, A, bytes); break;
-            case MSD_OP_SUM: launch_bucket<NT, 2>(nblocks, buf, vals, A, bytes); break;
-            case MSD_OP_OR: launch_bucket<NT, 3>(nblocks, buf, vals, A, bytes); break;
+            case MSD_OP_NONE: launch_bucket<SECOND, 0>(nblocks, buf, vals, A, bytes); break;
+            case MSD_OP_COUNT: launch_bucket<SECOND, 1>(nblocks, buf, vals, A, bytes); break;
+            case MSD_OP_SUM: launch_bucket<SECOND, 2>(nblocks, buf, vals, A, bytes); break;
+            case MSD_OP_OR: launch_bucket<SECOND, 3>(nblocks, buf, vals, A, bytes); break;
             default: BBK_REQUIRE(false, BBK_ERR_ARG, "bad reduce op");
         }
     }
@@ -1545,7 +1741,7 @@ struct MsdRunner {
         BBK_HIP(hipMemsetAsync(dbg.p, 0, 64, ctx->stream));
         BucketArgs A{boff.as<uint32_t>(), dcount.as<uint32_t>(), nullptr, (int)k, verbose ? dbg.as<uint32_t>() : nullptr};
         const double bb = (double)N * (rec + (has_val ? 4 : 0));
-        bucket_dispatch<BktCfg<W>::NT>(nbuckets, bufB.as<Key<W>>(), valB.as<uint32_t>(), A, bb);
+        bucket_dispatch<false>(nbuckets, bufB.as<Key<W>>(), valB.as<uint32_t>(), A, bb);
 
         // ---- buckets above CAP: a second pass with 512-thread workgroups (2 x CAP); what still does not
         // fit (a k-mer repeated > 12 k times in one bucket) is finished by the LSD path, one by one
@@ -1555,10 +1751,10 @@ struct MsdRunner {
         BBK_HIP(hipStreamSynchronize(ctx->stream));
         std::vector<uint32_t> big;
         uint64_t big_rec = 0;
-        // second chance: 8-byte keys -> the 512-thread sorting kernel (2 x 6144 records); wider keys whose
-        // first pass was the 4096-record hash kernel -> the 256-thread sorting kernel (6144 records)
-        // (8-byte keys: 2 x CAP; wider keys only gain over the 4096-record hash kernel)
-        const uint32_t cap2 = (W == 1 || use_hashidx_dedup()) ? BktCfg<W>::CAP2 : 0u;
+        // second chance: the ballot-ranked radix kernel with 512 threads -- buckets above the first pass's
+        // capacity (8-byte keys: 2 x CAP; wider keys: more than the 4096-record hash kernel) and buckets the
+        // distribution sort turned down for a crowded bin
+        const uint32_t cap2 = BktCfg<W>::CAP2;
         for (uint32_t b = 0; b < nbuckets; ++b)
             if (hd[b] == 0xFFFFFFFFu && hb[b + 1] - hb[b] <= cap2) {
                 big.push_back(b);
@@ -1569,7 +1765,7 @@ struct MsdRunner {
             BBK_HIP(hipMemcpyAsync(ids.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, ctx->stream));
             BucketArgs A2{boff.as<uint32_t>(), dcount.as<uint32_t>(), ids.as<uint32_t>(), (int)k, nullptr};
             const double b2 = (double)big_rec * (rec + (has_val ? 4 : 0));
-            bucket_dispatch<BktCfg<W>::NT2>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2,
+            bucket_dispatch<true>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2,
                                             /*allow_hash=*/false);
             BBK_HIP(hipMemcpyAsync(hd.data(), dcount.p, (size_t)nbuckets * 4, hipMemcpyDeviceToHost, ctx->stream));
             BBK_HIP(hipStreamSynchronize(ctx->stream));
