@@ -54,7 +54,8 @@ struct PartCfg {
 };
 // Fused extraction + level-1 partition: a lane owns one CHUNK of up to CH consecutive k-mer positions of
 // ONE read (8-byte keys: 8, rolled base by base; wider keys: 4), a workgroup 1024 chunks.
-constexpr int kRdThreads = 1024;
+constexpr int kRdThreads = 1024;      // scatter: big tiles, long per-bin runs
+constexpr int kRdHistThreads = 512;   // histogram: nothing is staged, four workgroups per CU hide the prologues
 constexpr int kRdSlots = 1024;  // reads of one tile whose cursor tables fit LDS
 constexpr int kRdWords = 2048;  // packed read words of one tile staged in LDS (150 bp reads need ~330)
 template <int W>
@@ -517,9 +518,10 @@ __device__ __forceinline__ void chunk_records(const ChunkWords C, uint32_t k_, c
 }
 
 template <int W, bool HAS_VAL, bool HIST_ONLY>
-__global__ __launch_bounds__(kRdThreads) void k_part_reads(ReadSrc S, PartLevel L, uint32_t *__restrict__ ghist,
+__global__ __launch_bounds__(HIST_ONLY ? kRdHistThreads : kRdThreads) void k_part_reads(ReadSrc S, PartLevel L, uint32_t *__restrict__ ghist,
                                                            uint32_t *__restrict__ cursor, Key<W> *__restrict__ out,
                                                            uint32_t *__restrict__ vout) {
+    constexpr int NT = HIST_ONLY ? kRdHistThreads : kRdThreads;  // chunks per tile = threads
     constexpr int CH = RdCfg<W>::CH, TILE = RdCfg<W>::TILE, MAXB = 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // layout: lhist | lstart | goff | scan[32] | U, where U is the read tables while extracting
@@ -539,8 +541,8 @@ __global__ __launch_bounds__(kRdThreads) void k_part_reads(ReadSrc S, PartLevel 
     const uint32_t tid = threadIdx.x;
     const uint32_t k_ = (uint32_t)S.k;
     const uint32_t nb = L.nb1;
-    const uint32_t ntiles = (uint32_t)((S.n_chunks + kRdThreads - 1) / kRdThreads);
-    for (uint32_t b = tid; b < nb; b += kRdThreads) lhist[b] = 0;
+    const uint32_t ntiles = (uint32_t)((S.n_chunks + NT - 1) / NT);
+    for (uint32_t b = tid; b < nb; b += NT) lhist[b] = 0;
 #ifdef BBK_PHASE_PROF
     unsigned long long t_prev = clock64();
 #else
@@ -550,9 +552,9 @@ __global__ __launch_bounds__(kRdThreads) void k_part_reads(ReadSrc S, PartLevel 
     // scatter: one tile per workgroup (grid == tiles).  Histogram: a workgroup walks many tiles and adds
     // its LDS histogram to the global one once (512 atomics per workgroup instead of per tile).
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const uint64_t c0 = (uint64_t)tile * kRdThreads;  // first chunk of the tile
+    const uint64_t c0 = (uint64_t)tile * NT;  // first chunk of the tile
     const uint64_t left = S.n_chunks - c0;
-    const uint32_t nch = left < (uint64_t)kRdThreads ? (uint32_t)left : (uint32_t)kRdThreads;
+    const uint32_t nch = left < (uint64_t)NT ? (uint32_t)left : (uint32_t)NT;
     const uint32_t r0 = S.tile_read[tile], r1 = S.tile_read[tile + 1];
     const uint32_t nr = r1 - r0 + 1;  // reads r0..r1 inclusive
 
@@ -562,14 +564,14 @@ __global__ __launch_bounds__(kRdThreads) void k_part_reads(ReadSrc S, PartLevel 
     const uint64_t w_r0 = S.woff[r0], w_r1 = S.woff[r1];
     const uint64_t wbase = w_r0 + ((p0 ? p0 - 1u : 0u) >> 5);
     const uint32_t len1 = S.len[r1];
-    const uint64_t span1 = (c0 + kRdThreads - S.coff[r1]) * CH + k_;  // base index the tile can reach in r1
+    const uint64_t span1 = (c0 + NT - S.coff[r1]) * CH + k_;  // base index the tile can reach in r1
     const uint32_t lastb1 = len1 ? (uint32_t)(span1 < (uint64_t)(len1 - 1u) ? span1 : (uint64_t)(len1 - 1u)) : 0u;
     const uint64_t wend = w_r1 + (len1 ? (lastb1 >> 5) + 1u : 0u);
     bool fast = nr <= (uint32_t)kRdSlots && wend >= wbase && wend - wbase <= (uint64_t)kRdWords;
     const uint32_t wspan = fast ? (uint32_t)(wend - wbase) : 0u;
     if (fast) {
         bool bad = false;
-        for (uint32_t i = tid; i <= nr; i += kRdThreads) {
+        for (uint32_t i = tid; i <= nr; i += NT) {
             const uint64_t rr = (uint64_t)r0 + i;  // <= n_reads (coff holds n_reads + 1 entries)
             s_rel[i] = (int32_t)(int64_t)(S.coff[rr] - c0);
             if (i < nr) {
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(kRdThreads) void k_part_reads(ReadSrc S, PartLevel 
                 if (i + 1 < nr && wo + ((ln + 31u) >> 5) > wend) bad = true;
             }
         }
-        for (uint32_t i = tid; i < wspan; i += kRdThreads) s_words[i] = S.words[wbase + i];
+        for (uint32_t i = tid; i < wspan; i += NT) s_words[i] = S.words[wbase + i];
         fast = !__syncthreads_or(bad);
     } else {
         __syncthreads();
@@ -626,13 +628,13 @@ __global__ __launch_bounds__(kRdThreads) void k_part_reads(ReadSrc S, PartLevel 
 
     if constexpr (!HIST_ONLY) {
         BBK_PH(0, 1, t_prev);  // extraction + LDS ranking
-        part_tail<W, CH, kRdThreads, MAXB, HAS_VAL>(keys, vals, binrank, lhist, lstart, goff, scan_tmp, stage, vstage, nb,
+        part_tail<W, CH, NT, MAXB, HAS_VAL>(keys, vals, binrank, lhist, lstart, goff, scan_tmp, stage, vstage, nb,
                                                     0ull, L, cursor, out, vout, 0, t_prev);
         return;
     }
     }
     if (HIST_ONLY) {
-        for (uint32_t b = tid; b < nb; b += kRdThreads) {
+        for (uint32_t b = tid; b < nb; b += NT) {
             const uint32_t c = lhist[b];
             if (c) atomicAdd(&ghist[b], c);
         }
@@ -1461,10 +1463,10 @@ struct MsdRunner {
         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)sm));
         // histogram: ~8 resident-workgroup rounds, each workgroup walks its tiles and flushes once
-        static const char *eg = getenv("BBK_HIST_GRID");
-        const uint32_t grid = HIST ? std::min<uint32_t>(ntiles, eg ? (uint32_t)atoi(eg) : 4096u) : ntiles;
+        const uint32_t grid = HIST ? std::min<uint32_t>(ntiles, 8192u) : ntiles;
         KernelTimer t(ctx, fam, bytes);
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(kRdThreads), sm, ctx->stream, S, L, ghist, cursor, out, vout);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(HIST ? kRdHistThreads : kRdThreads), sm, ctx->stream, S, L, ghist, cursor,
+                           out, vout);
         check_launch(fam);
     }
 
@@ -1621,18 +1623,27 @@ struct MsdRunner {
         }
         PartLevel L1{1, b1, nb1, dmode, w0bits, nullptr, nullptr, sel_bits, sel_val};
 
-        // level-1 tiles cover the whole instance space; a range pass keeps its share of every tile
+        // level-1 tiles cover the whole instance space; a range pass keeps its share of every tile.  Reads:
+        // a tile is `threads` chunks, so the histogram (512 threads) and the scatter (1024) have their own tables
         const uint32_t ntiles1 = from_reads ? (uint32_t)((n_chunks + kRdThreads - 1) / kRdThreads)
                                             : (uint32_t)((Ntot + kPartTileK - 1) / kPartTileK);
-        ReadSrc S{};
+        const uint32_t ntiles1h = (uint32_t)((n_chunks + kRdHistThreads - 1) / kRdHistThreads);
+        DevBuf tile_read_h;
+        ReadSrc S{}, Sh{};
         if (from_reads) {
             tile_read.alloc(((size_t)ntiles1 + 2) * sizeof(uint32_t));
+            tile_read_h.alloc(((size_t)ntiles1h + 2) * sizeof(uint32_t));
             hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1 + 1 + 255) / 256), dim3(256), 0, ctx->stream,
                                coff.as<uint64_t>(), rd->n, (uint64_t)ntiles1, (uint32_t)kRdThreads,
                                tile_read.as<uint32_t>());
+            hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1h + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                               coff.as<uint64_t>(), rd->n, (uint64_t)ntiles1h, (uint32_t)kRdHistThreads,
+                               tile_read_h.as<uint32_t>());
             check_launch("k_tile_reads");
             S = ReadSrc{rd->d_words, rd->d_woff, rd->d_len, coff.as<uint64_t>(), tile_read.as<uint32_t>(), rd->n, n_chunks,
                         (int)k};
+            Sh = S;
+            Sh.tile_read = tile_read_h.as<uint32_t>();
         }
         TileMap M1{nullptr, nullptr, 1, Ntot, 0, 1, nullptr};
 
@@ -1643,7 +1654,7 @@ struct MsdRunner {
         if (nb1 > 1 || sel_bits) {
             const double hb = from_reads ? (double)rd->n_words * 8 : (double)N * rec;
             if (from_reads) {
-                launch_part_reads<false, true>("part_hist1_reads", hb, ntiles1, S, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+                launch_part_reads<false, true>("part_hist1_reads", hb, ntiles1h, Sh, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
             } else {
                 launch_part<false, true>("part_hist1_keys", hb, ntiles1, kin, nullptr, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
             }
