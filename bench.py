@@ -7,7 +7,7 @@ Metric (BASELINE.json): distinct k-mers/sec, k=21, 150 bp synthetic reads.
 N=1 workload = BASELINE.json configs[1]: 10 M x 150 bp uniform reads (50x coverage of a
 30 Mbp random genome, 0.5 % substitutions), k-mer count only, reads already packed in HBM.
 One "step" = one full pass of the hot path over the batch: 2-bit extraction of canonical
-k-mers -> radix sort -> unique (+counts off) -> both-strand expansion -> reference
+k-mers -> hash-partitioned dedup -> both-strand expansion -> sort into the reference
 (final_kmers) order, result left in HBM.  value = |final_kmers records| * N / time.
 
 N>1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank holds its own
@@ -130,12 +130,11 @@ def main():
     def step():
         """Returns (#records of this rank's part of the result, keep-alive)."""
         if world == 1:
-            s = ctx.count(reads, k, B.BOTH_STRANDS)
-            n = len(s)
-            out = torch.empty((n, nw), dtype=torch.int64, device=dev)
-            s.export_to(out, B.ORDER_REFERENCE_BUCKETS16)
-            s.free()
-            return n, out
+            # the set is built in the final_kmers order (what spades-kmercount leaves on disk) and stays in HBM
+            s = ctx.count(reads, k, B.BOTH_STRANDS | B.REFERENCE_ORDER)
+            ptr, order = s.device_keys()
+            assert order == B.ORDER_REFERENCE_BUCKETS16 and (ptr or len(s) == 0)
+            return len(s), s
         both = D.sharded_count(ctx, reads, k, both_strands=True)
         n2 = len(both)
         out = torch.empty((n2, nw), dtype=torch.int64, device=dev)
@@ -148,8 +147,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def drop(x):
+        if hasattr(x, "free"):
+            x.free()
+
     for _ in range(args.warmup):
         n_rec, keep = step()
+        drop(keep)
         del keep
     ctx.profile(True)
     ctx.profile_reset()
@@ -157,6 +161,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         n_rec, keep = step()
+        drop(keep)
         del keep
     fence()
     dt = time.perf_counter() - t0

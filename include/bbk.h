@@ -97,7 +97,15 @@ void bbk_reads_free(bbk_reads *r);
 #define BBK_WITH_COUNTS 4u  /* keep multiplicities (occurrences over reads + rc(reads)) */
 #define BBK_UNSORTED 8u     /* distinct set only, internal (hash-bucket) order: enough for the owner partition,
                                bbk_kmerset_both_strands and a later bbk_kmerset_from_device; skips the sort */
+#define BBK_REFERENCE_ORDER 16u /* store the set in the final_kmers order (BBK_ORDER_REFERENCE_BUCKETS16) instead of
+                                  ascending: what CountAll(16, ..., merge=true) leaves on disk
+                                  (projects/kmercount/main.cpp:214-219).  Exporting in that order is then a plain copy
+                                  and bbk_kmerset_keys() is the result itself */
 int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, bbk_kmerset **out);
+/* Device pointer to the records of the set (size * words u64) in the order it is stored in; valid until
+ * bbk_kmerset_free.  *order receives BBK_ORDER_SORTED / BBK_ORDER_REFERENCE_BUCKETS16, or 0xFFFFFFFF for a
+ * BBK_UNSORTED set. */
+const void *bbk_kmerset_keys(const bbk_kmerset *s, unsigned *order);
 /* Sort + unique an array of k-mer records already in HBM (n records of bbk_words(k) u64 each,
  * optional u32 multiplicities that are summed).  Used after the multi-GPU exchange. */
 int bbk_kmerset_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, unsigned k,

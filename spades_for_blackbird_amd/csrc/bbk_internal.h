@@ -246,6 +246,7 @@ struct bbk_kmerset {
     bbk::DevBuf counts;      // n u32 (optional)
     bool has_counts = false;
     bool sorted = true;      // false: distinct but in hash-bucket order (BBK_UNSORTED)
+    bool ref_order = false;  // true: final_kmers order (16 XXH3 buckets, ascending inside) instead of ascending
 };
 
 struct bbk_extindex {

@@ -108,15 +108,23 @@ __global__ __launch_bounds__(256) void k_extract(const uint64_t *__restrict__ wo
 }
 
 // out[2i] = key, out[2i+1] = rc(key): the both-strand set of spades-kmercount
-template <int W>
+// TAG (8-byte keys with >= 4 spare bits): the XXH3 bucket of 16 (KMerSegmentPolicy, kmer_buckets.hpp:28-33) is
+// put right above the k-mer (bits 2k..2k+3), so that one ascending sort of the tagged keys yields the
+// final_kmers order
+template <int W, bool TAG>
 __global__ __launch_bounds__(256) void k_expand_rc(const Key<W> *__restrict__ in, const uint32_t *__restrict__ cin,
                                                   uint64_t n, int k, Key<W> *__restrict__ out,
                                                   uint32_t *__restrict__ cout) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Key<W> x = in[i];
+    Key<W> x = in[i];
+    Key<W> y = kmer_rc<W>(x, k);
+    if (TAG) {
+        x.w[0] |= __umul64hi(xxh3_64<W>(x), 16ull) << (2 * k);
+        y.w[0] |= __umul64hi(xxh3_64<W>(y), 16ull) << (2 * k);
+    }
     out[2 * i] = x;
-    out[2 * i + 1] = kmer_rc<W>(x, k);
+    out[2 * i + 1] = y;
     if (cin) {
         const uint32_t c = cin[i];
         cout[2 * i] = c;
@@ -140,11 +148,15 @@ static void launch_extract(bbk_ctx *ctx, const bbk_reads *rd, const uint64_t *ko
 
 template <int W>
 static void launch_expand(bbk_ctx *ctx, const void *in, const uint32_t *cin, uint64_t n, int k, void *out,
-                          uint32_t *cout) {
+                          uint32_t *cout, bool tag) {
     if (n == 0) return;
     KernelTimer t(ctx, "expand", 3.0 * (double)n * sizeof(Key<W>));
-    hipLaunchKernelGGL(k_expand_rc<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const Key<W> *)in, cin, n, k, (Key<W> *)out, cout);
+    if (tag)
+        hipLaunchKernelGGL((k_expand_rc<W, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const Key<W> *)in, cin, n, k, (Key<W> *)out, cout);
+    else
+        hipLaunchKernelGGL((k_expand_rc<W, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const Key<W> *)in, cin, n, k, (Key<W> *)out, cout);
     check_launch("k_expand_rc");
 }
 
@@ -231,8 +243,9 @@ void count_canonical(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_ma
 // canon U rc(canon): expand, sort, unique.  A k-mer equal to its own RC (even k) appears twice
 // and is merged by unique; its count doubles, as in the reference where both strands of such an
 // occurrence are counted.
+// want_ref: leave the set in the final_kmers order when that is free (tagged sort); s.ref_order tells.
 static void expand_both_strands(bbk_ctx *ctx, unsigned k, const DevBuf &ck, const DevBuf *cv, uint64_t D,
-                                bbk_kmerset &s) {
+                                bbk_kmerset &s, bool want_ref = false) {
     const bool wc = cv != nullptr;
     const int W = (int)words_of(k);
     const size_t rec = (size_t)W * 8;
@@ -248,17 +261,23 @@ static void expand_both_strands(bbk_ctx *ctx, unsigned k, const DevBuf &ck, cons
         ec.alloc(2 * D * 4);
         ect.alloc(2 * D * 4);
     }
-    BBK_DISPATCH_W(W, launch_expand<W_>(ctx, ck.p, wc ? cv->as<uint32_t>() : nullptr, D, (int)k, e.p,
-                                        wc ? ec.as<uint32_t>() : nullptr));
-    if (msd_enabled()) {
-        MsdOutput m;
-        if (msd_sort_reduce(ctx, k, MSD_KEYS, wc ? MSD_OP_SUM : MSD_OP_NONE, nullptr, e.p,
-                            wc ? ec.as<uint32_t>() : nullptr, 2 * D, false, m)) {
-            s.n = m.n;
-            s.keys = std::move(m.keys);
-            if (wc) s.counts = std::move(m.vals);
-            return;
+    bool tag = want_ref && W == 1 && 2 * k + 4 <= 64 && msd_enabled();
+    for (;;) {
+        BBK_DISPATCH_W(W, launch_expand<W_>(ctx, ck.p, wc ? cv->as<uint32_t>() : nullptr, D, (int)k, e.p,
+                                            wc ? ec.as<uint32_t>() : nullptr, tag));
+        if (msd_enabled()) {
+            MsdOutput m;
+            if (msd_sort_reduce(ctx, k, MSD_KEYS, wc ? MSD_OP_SUM : MSD_OP_NONE, nullptr, e.p,
+                                wc ? ec.as<uint32_t>() : nullptr, 2 * D, false, m, tag ? 4u : 0u)) {
+                s.n = m.n;
+                s.keys = std::move(m.keys);
+                if (wc) s.counts = std::move(m.vals);
+                s.ref_order = tag;
+                return;
+            }
         }
+        if (!tag) break;
+        tag = false;  // the tagged sort declined: expand again without tags and take the generic path
     }
     sort_records(ctx, W, e.p, et.p, wc ? ec.as<uint32_t>() : nullptr, wc ? ect.as<uint32_t>() : nullptr, 2 * D,
                  key_passes(k));
@@ -294,6 +313,9 @@ int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, 
         const bool both = (flags & BBK_BOTH_STRANDS) != 0, canon = (flags & BBK_CANONICAL) != 0;
         BBK_REQUIRE(both != canon, BBK_ERR_ARG, "bbk_count: pass exactly one of BBK_BOTH_STRANDS / BBK_CANONICAL");
         const bool wc = (flags & BBK_WITH_COUNTS) != 0;
+        const bool want_ref = (flags & BBK_REFERENCE_ORDER) != 0;
+        BBK_REQUIRE(!(want_ref && (flags & BBK_UNSORTED)), BBK_ERR_ARG,
+                    "bbk_count: BBK_REFERENCE_ORDER and BBK_UNSORTED exclude each other");
         BBK_HIP(hipSetDevice(ctx->device));
         auto s = std::make_unique<bbk_kmerset>();
         s->k = k;
@@ -302,13 +324,28 @@ int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, 
         s->has_counts = wc;
         DevBuf ck, cv;
         uint64_t D = 0, N = 0;
+        // an ascending set -> the final_kmers order: one stable pass on the XXH3 bucket
+        auto to_ref_order = [&](bbk_kmerset &ks) {
+            if (!want_ref || ks.ref_order) return;
+            if (ks.n) {
+                const PassDesc pd{1, 0, 0, 8, 16};
+                DevBuf nk(ks.n * (size_t)ks.W * 8), nc;
+                if (wc) nc.alloc(ks.n * 4);
+                partition_records(ctx, (int)ks.W, ks.keys.p, nk.p, wc ? ks.counts.as<uint32_t>() : nullptr,
+                                  wc ? nc.as<uint32_t>() : nullptr, ks.n, pd);
+                ks.keys = std::move(nk);
+                if (wc) ks.counts = std::move(nc);
+            }
+            ks.ref_order = true;
+        };
         if (both && msd_enabled()) {
             // fast path: hash-partitioned dedup of the canonical stream, then expand and sort once
             MsdOutput a;
             if (msd_sort_reduce(ctx, k, MSD_HASH, wc ? MSD_OP_COUNT : MSD_OP_NONE, reads, nullptr, nullptr, 0, false,
                                 a)) {
                 s->instances = 2 * a.instances;
-                expand_both_strands(ctx, k, a.keys, wc ? &a.vals : nullptr, a.n, *s);
+                expand_both_strands(ctx, k, a.keys, wc ? &a.vals : nullptr, a.n, *s, want_ref);
+                to_ref_order(*s);
                 *out = s.release();
                 return;
             }
@@ -333,10 +370,17 @@ int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, 
             s->keys = std::move(ck);
             if (wc) s->counts = std::move(cv);
         } else {
-            expand_both_strands(ctx, k, ck, wc ? &cv : nullptr, D, *s);
+            expand_both_strands(ctx, k, ck, wc ? &cv : nullptr, D, *s, want_ref);
         }
+        to_ref_order(*s);
         *out = s.release();
     });
+}
+
+const void *bbk_kmerset_keys(const bbk_kmerset *s, unsigned *order) {
+    if (!s) return nullptr;
+    if (order) *order = !s->sorted ? 0xFFFFFFFFu : (s->ref_order ? BBK_ORDER_REFERENCE_BUCKETS16 : BBK_ORDER_SORTED);
+    return s->keys.p;
 }
 
 int bbk_kmerset_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, unsigned k,
@@ -438,7 +482,23 @@ static void export_ordered(bbk_ctx *ctx, const bbk_kmerset *s, const PassDesc *p
     if (h_counts && pd) memset(h_counts, 0, pd->nb * sizeof(uint64_t));
     if (s->n == 0) return;
     const bool wc = s->has_counts && dst_counts;
-    if (!pd) {
+    if (s->ref_order && !pd) {
+        // ascending export of a set stored in the final_kmers order: sort a copy (not a hot path)
+        DevBuf a(s->n * rec), b(s->n * rec), ca, cb;
+        BBK_HIP(hipMemcpyAsync(a.p, s->keys.p, s->n * rec, hipMemcpyDeviceToDevice, ctx->stream));
+        if (wc) {
+            ca.alloc(s->n * 4);
+            cb.alloc(s->n * 4);
+            BBK_HIP(hipMemcpyAsync(ca.p, s->counts.p, s->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        sort_records(ctx, (int)s->W, a.p, b.p, wc ? ca.as<uint32_t>() : nullptr, wc ? cb.as<uint32_t>() : nullptr, s->n,
+                     key_passes(s->k));
+        BBK_HIP(hipMemcpyAsync(dst_keys, a.p, s->n * rec, hipMemcpyDefault, ctx->stream));
+        if (wc) BBK_HIP(hipMemcpyAsync(dst_counts, ca.p, s->n * 4, hipMemcpyDefault, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        return;
+    }
+    if (!pd || (s->ref_order && pd->kind == 1 && pd->nb == 16)) {  // stored in the requested order: plain copy
         BBK_HIP(hipMemcpyAsync(dst_keys, s->keys.p, s->n * rec, hipMemcpyDefault, ctx->stream));
         if (wc) BBK_HIP(hipMemcpyAsync(dst_counts, s->counts.p, s->n * 4, hipMemcpyDefault, ctx->stream));
         BBK_HIP(hipStreamSynchronize(ctx->stream));

@@ -22,7 +22,10 @@ struct MsdOutput {
 // the fly, with_mask adds the InOutMask bits of every occurrence as payload) or from a key array
 // (d_keys[, d_vals], n).  Returns false when this path declines (key width, size, too much
 // overflow): the caller then uses the LSD path.  MSD_KEYS output is globally ascending.
+// tag_bits > 0 (8-byte keys, key array input, MSD_KEYS): bits [2k, 2k + tag_bits) of every key hold a tag
+// that is more significant than the k-mer (the caller put it there); the records are ordered by
+// (tag, k-mer) and the tag is cleared in the output.
 bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_reads *rd, const void *d_keys,
-                     const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out);
+                     const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out, unsigned tag_bits = 0);
 
 }  // namespace bbk

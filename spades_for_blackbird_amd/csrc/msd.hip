@@ -1360,7 +1360,8 @@ template <int W, bool HAS_VAL>
 __global__ __launch_bounds__(256) void k_compact(const Key<W> *__restrict__ buf, const uint32_t *__restrict__ vals,
                                                 const uint32_t *__restrict__ boff, const uint32_t *__restrict__ dcount,
                                                 const uint64_t *__restrict__ doff, uint32_t nbuckets,
-                                                Key<W> *__restrict__ out, uint32_t *__restrict__ vout) {
+                                                Key<W> *__restrict__ out, uint32_t *__restrict__ vout,
+                                                uint64_t mask0) {  // cleared from word 0 (sort tag), else ~0
     const uint32_t b = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (b >= nbuckets) return;
     const int lane = threadIdx.x & 63;
@@ -1368,7 +1369,9 @@ __global__ __launch_bounds__(256) void k_compact(const Key<W> *__restrict__ buf,
     const uint32_t s = boff[b];
     const uint64_t d = doff[b];
     for (uint32_t i = lane; i < c; i += 64) {
-        key_store<W>(&out[d + i], key_load<W>(&buf[s + i]));
+        Key<W> key = key_load<W>(&buf[s + i]);
+        key.w[0] &= mask0;
+        key_store<W>(&out[d + i], key);
         if (HAS_VAL) vout[d + i] = vals[s + i];
     }
 }
@@ -1429,6 +1432,7 @@ struct MsdRunner {
     int dmode;
     int op;        // MSD_OP_*
     bool in_vals;  // records carry a payload from the start (mask extraction or input counts)
+    uint64_t strip_mask = ~0ull;  // tagged sort: bits of word 0 that survive in the output
 
     template <bool HAS_VAL, bool HIST>
     void launch_part(const char *fam, double bytes, uint32_t ntiles, const Key<W> *in, const uint32_t *vin, TileMap M,
@@ -1837,11 +1841,11 @@ struct MsdRunner {
             if (out_vals)
                 hipLaunchKernelGGL((k_compact<W, true>), dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<Key<W>>(),
                                    valB.as<uint32_t>(), boff.as<uint32_t>(), dcount.as<uint32_t>(), d64.as<uint64_t>(),
-                                   nbuckets, out.keys.as<Key<W>>(), out.vals.as<uint32_t>());
+                                   nbuckets, out.keys.as<Key<W>>(), out.vals.as<uint32_t>(), strip_mask);
             else
                 hipLaunchKernelGGL((k_compact<W, false>), dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<Key<W>>(),
                                    (const uint32_t *)nullptr, boff.as<uint32_t>(), dcount.as<uint32_t>(),
-                                   d64.as<uint64_t>(), nbuckets, out.keys.as<Key<W>>(), (uint32_t *)nullptr);
+                                   d64.as<uint64_t>(), nbuckets, out.keys.as<Key<W>>(), (uint32_t *)nullptr, strip_mask);
             check_launch("k_compact");
         }
         // bucket table for lookups (HASH mode): offsets of every bucket in the dense output
@@ -1909,8 +1913,17 @@ static void dump_phases() {
 #endif
 
 bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_reads *rd, const void *d_keys,
-                     const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out) {
+                     const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out, unsigned tag_bits) {
     const int W = (int)words_of(k);
+    if (tag_bits) {
+        // the tag sits right above the k-mer (bits [2k, 2k + tag_bits)): sort as a (k + tag_bits/2)-mer, clear the
+        // tag on the way out
+        BBK_REQUIRE(W == 1 && rd == nullptr && dmode == MSD_KEYS && tag_bits % 2 == 0 && 2 * k + tag_bits <= 64,
+                    BBK_ERR_INTERNAL, "tagged sort needs 8-byte keys with %u spare bits", tag_bits);
+        MsdRunner<1> r{ctx, k + tag_bits / 2, dmode, op, d_vals != nullptr};
+        r.strip_mask = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+        return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
+    }
 #ifdef BBK_PHASE_PROF
     struct Dump {
         ~Dump() { dump_phases(); }

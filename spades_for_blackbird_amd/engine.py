@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-BOTH_STRANDS, CANONICAL, WITH_COUNTS, UNSORTED = 1, 2, 4, 8
+BOTH_STRANDS, CANONICAL, WITH_COUNTS, UNSORTED, REFERENCE_ORDER = 1, 2, 4, 8, 16
 ORDER_SORTED, ORDER_REFERENCE_BUCKETS16 = 0, 1
 
 # every symbol include/bbk.h declares (checked by tests/test_abi.py)
@@ -17,7 +17,7 @@ SYMBOLS = [
     "bbk_reads_from_ascii", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_from_spades_binary",
     "bbk_reads_write_spades_binary", "bbk_reads_count", "bbk_reads_bases",
     "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
-    "bbk_count", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k",
+    "bbk_count", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k", "bbk_kmerset_keys",
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_free",
@@ -76,6 +76,8 @@ def load_library():
     L.bbk_words.argtypes = [C.c_uint]
     L.bbk_kmerset_size.restype = u64
     L.bbk_kmerset_size.argtypes = [vp]
+    L.bbk_kmerset_keys.restype = vp
+    L.bbk_kmerset_keys.argtypes = [vp, C.POINTER(C.c_uint)]
     L.bbk_kmerset_k.restype = C.c_uint
     L.bbk_kmerset_k.argtypes = [vp]
     L.bbk_kmerset_instances.restype = u64
@@ -293,6 +295,12 @@ class KMerSet(_Handle):
     @property
     def instances(self):
         return int(self._L.bbk_kmerset_instances(self._h))
+
+    def device_keys(self):
+        """(device pointer of the records, order they are stored in); valid until the set is freed."""
+        o = C.c_uint(0)
+        p = self._L.bbk_kmerset_keys(self._h, C.byref(o))
+        return p, int(o.value)
 
     def both_strands(self):
         h = C.c_void_p()

@@ -269,3 +269,35 @@ def test_spades_binary_read_cache(ctx, tmp_path):
     a = ctx.count(r, 21, B.BOTH_STRANDS).export(B.ORDER_REFERENCE_BUCKETS16)
     b = ctx.count(r2, 21, B.BOTH_STRANDS).export(B.ORDER_REFERENCE_BUCKETS16)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("k", [4, 21, 30, 31, 32, 55, 77])
+def test_reference_order_flag(ctx, golden, golden_dir, k):
+    """BBK_REFERENCE_ORDER stores the set in the final_kmers order: exporting in that order is a copy and must
+    equal the oracle (and, for the toy data, the reference's own md5); the ascending export must still be
+    ascending.  k <= 30 takes the tagged-sort path, larger k the generic reorder."""
+    reads = synth_reads(600, read_len=150, genome_len=5000, sub_rate=0.01, seed=100 + k, n_rate=0.001)
+    reads += ["", "ACGT" * 40, "T" * 150]
+    exp, expc = O.kmercount(reads, k, 16, 2, with_counts=True)
+    for wc in (False, True):
+        s = ctx.count(ctx.reads_from_ascii(reads), k, B.BOTH_STRANDS | B.REFERENCE_ORDER | (B.WITH_COUNTS if wc else 0))
+        ptr, order = s.device_keys()
+        assert order == B.ORDER_REFERENCE_BUCKETS16 and ptr
+        if wc:
+            got, gotc = s.export(B.ORDER_REFERENCE_BUCKETS16, with_counts=True)
+            assert np.array_equal(gotc, expc)
+        else:
+            got = s.export(B.ORDER_REFERENCE_BUCKETS16)
+        assert np.array_equal(got, exp)
+        asc = s.export(B.ORDER_SORTED)
+        ref = ctx.count(ctx.reads_from_ascii(reads), k, B.BOTH_STRANDS).export(B.ORDER_SORTED)
+        assert np.array_equal(asc, ref)
+    if k == 21:
+        g = golden["toy_kmercount"]
+        toy = []
+        for f in g["files"]:
+            toy += read_fastq_gz(os.path.join(golden_dir, f))
+        s = ctx.count(ctx.reads_from_ascii(toy), 21, B.BOTH_STRANDS | B.REFERENCE_ORDER)
+        assert hashlib.md5(s.export(B.ORDER_REFERENCE_BUCKETS16).tobytes()).hexdigest() == g["k21"]["md5"]
+    with pytest.raises(B.BBKError):
+        ctx.count(ctx.reads_from_ascii(reads), k, B.CANONICAL | B.REFERENCE_ORDER | B.UNSORTED)
