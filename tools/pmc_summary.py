@@ -24,7 +24,7 @@ FAMILY = [  # k_part_reads<W, HAS_VAL, HIST_ONLY>, k_part<W, HAS_VAL, HIST_ONLY,
     (r"k_part<\d, (true|false), true, true>", "part_hist1_keys"),
     (r"k_part<\d, (true|false), true, false>", "part_hist2"),
     (r"k_bucket_hash", "lds_dedup"),
-    (r"k_bucket<", "lds_sort"),
+    (r"k_bucket(_dist)?<", "lds_sort"),
     (r"k_compact", "compact"),
     (r"k_scatter<", "scatter"),
     (r"k_hist<", "hist"),
