@@ -230,14 +230,16 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
     (void)prof_kind;
     (void)t_prev;
     uint32_t staged = 0;
+    constexpr int BPT = (MAXB + THREADS - 1) / THREADS;
+    uint32_t greserve[BPT], cq[BPT], ex0 = 0;
     {
-        constexpr int BPT = (MAXB + THREADS - 1) / THREADS;
         uint32_t c[BPT];
         uint32_t v = 0;
 #pragma unroll
         for (int q = 0; q < BPT; ++q) {
             const uint32_t bq = BPT * tid + q;
             c[q] = bq < nb ? lhist[bq] : 0;
+            cq[q] = c[q];
             v += c[q];
         }
         const int lane = tid & 63, wave = tid >> 6;
@@ -255,19 +257,19 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
             all += scan_tmp[w];
         }
         staged = all;  // records of this tile that take part
-        uint32_t ex = wbase + incl - v;
+        ex0 = wbase + incl - v;
+        uint32_t ex = ex0;
 #pragma unroll
         for (int q = 0; q < BPT; ++q) {
             const uint32_t bq = BPT * tid + q;
-            if (bq < nb) {
-                lstart[bq] = ex;
-                goff[bq] = (c[q] ? atomicAdd(&cursor[gbin0 + bq], c[q]) : 0u) - ex;
-            }
+            if (bq < nb) lstart[bq] = ex;
+            // the reservation is issued now and consumed after the LDS reorder: its latency overlaps that phase
+            greserve[q] = (bq < nb && c[q]) ? atomicAdd(&cursor[gbin0 + bq], c[q]) : 0u;
             ex += c[q];
         }
     }
     __syncthreads();
-    BBK_PH(prof_kind, 2, t_prev);  // scan + global reservation
+    BBK_PH(prof_kind, 2, t_prev);  // scan (+ reservation issue)
 
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -275,6 +277,15 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
             const uint32_t pos = lstart[binrank[i] >> 16] + (binrank[i] & 0xFFFFu);
             key_store<W>(&stage[pos], keys[i]);
             if (HAS_VAL) vstage[pos] = vals[i];
+        }
+    }
+    {
+        uint32_t ex = ex0;
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) {
+            const uint32_t bq = BPT * tid + q;
+            if (bq < nb) goff[bq] = greserve[q] - ex;
+            ex += cq[q];
         }
     }
     __syncthreads();
@@ -394,6 +405,15 @@ __global__ __launch_bounds__(PartCfg<W>::THREADS) void k_part(const Key<W> *__re
         const uint64_t at = begin + (local < count ? local : count - 1u);
         keys[i] = key_load<W>(&in[at]);
         vals[i] = HAS_VAL ? vin[at] : 0u;
+    }
+    // keep the records in registers: otherwise hipcc re-loads them from (restrict, read-only) memory for the LDS
+    // reorder, which doubles the L2 traffic and, vmcnt being in-order, puts the reservation atomics issued in
+    // between back on the critical path
+#pragma unroll
+    for (int i = 0; i < kPartItems; ++i) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) asm volatile("" : "+v"(keys[i].w[w]));
+        if (HAS_VAL) asm volatile("" : "+v"(vals[i]));
     }
 #pragma unroll
     for (int i = 0; i < kPartItems; ++i) {

@@ -77,7 +77,7 @@ int main(int argc, char **argv) {
     uint64_t n_reads = 0;
     bbk_reads *reads = load_reads(ctx, files, &n_reads);
     bbk_kmerset *set = nullptr;
-    check(bbk_count(ctx, reads, K, BBK_BOTH_STRANDS, &set), "bbk_count");
+    check(bbk_count(ctx, reads, K, BBK_BOTH_STRANDS | BBK_REFERENCE_ORDER, &set), "bbk_count");  // built in the final_kmers order
     // same line as KMerDiskCounter::Count (common/utils/kmer_mph/kmer_index_builder.hpp:260)
     info("K-mer counting done. There are %llu kmers in total.", (unsigned long long)bbk_kmerset_size(set));
     if (!workdir.empty()) mkdir(workdir.c_str(), 0755);
