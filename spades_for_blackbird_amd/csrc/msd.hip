@@ -111,7 +111,7 @@ struct ReadSrc {
     const uint64_t *woff;
     const uint32_t *len;
     const uint64_t *coff;       // exclusive scan of chunks per read (n_reads + 1)
-    const uint32_t *tile_read;  // read holding the first chunk of every tile (ntiles + 1)
+    const struct RdTile *tiles;  // per tile: its reads and the window of packed words to stage (k_tile_reads)
     uint64_t n_reads;
     uint64_t n_chunks;
     int k;
@@ -128,19 +128,53 @@ __device__ inline uint32_t read_of(const int32_t *s_rel, uint32_t nr, int32_t c)
     return lo;
 }
 
-// read holding the first unit (chunk) of every tile: largest r with off[r] <= t * tile
-__global__ void k_tile_reads(const uint64_t *__restrict__ off, uint64_t n_reads, uint64_t n_tiles, uint32_t tile,
-                             uint32_t *__restrict__ tile_read) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > n_tiles) return;
-    const uint64_t j = t * (uint64_t)tile;
+// What a workgroup of k_part_reads needs to start on a tile, precomputed so that its prologue is ONE scalar load
+// followed by the coalesced table/word copies instead of three dependent global round trips.
+struct RdTile {
+    uint64_t wbase;  // first packed word of the staged window
+    uint32_t r0;     // read holding the tile's first chunk
+    uint32_t nr;     // reads r0 .. r0+nr-1 own chunks of (or lie inside) the tile
+    uint32_t wspan;  // words of the window; 0xFFFFFFFF: does not fit LDS / not in read order (global-memory path)
+    uint32_t pad;
+};
+
+// largest r in [0, n_reads) with off[r] <= j
+__device__ inline uint64_t read_at(const uint64_t *__restrict__ off, uint64_t n_reads, uint64_t j) {
     uint64_t lo = 0, hi = n_reads;
     while (hi - lo > 1) {
         const uint64_t mid = (lo + hi) >> 1;
         if (off[mid] <= j) lo = mid;
         else hi = mid;
     }
-    tile_read[t] = (uint32_t)lo;
+    return lo;
+}
+
+// one thread per tile of `tile` chunks (a chunk = ch k-mer positions of one read)
+__global__ void k_tile_reads(const uint64_t *__restrict__ coff, const uint64_t *__restrict__ woff,
+                             const uint32_t *__restrict__ len, uint64_t n_reads, uint64_t n_tiles, uint32_t tile,
+                             uint32_t ch, uint32_t k, uint32_t max_reads, uint32_t max_words,
+                             RdTile *__restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint64_t c0 = t * (uint64_t)tile;
+    const uint64_t r0 = read_at(coff, n_reads, c0), r1 = read_at(coff, n_reads, c0 + tile);
+    // staged word window: from the word of the first base this tile touches in r0 (one base before the chunk,
+    // for the incoming-edge bit) to the last word it can touch in r1
+    const uint32_t p0 = (uint32_t)(c0 - coff[r0]) * ch;
+    const uint64_t wbase = woff[r0] + ((p0 ? p0 - 1u : 0u) >> 5);
+    const uint32_t len1 = len[r1];
+    const uint64_t span1 = (c0 + tile - coff[r1]) * ch + k;  // base index the tile can reach in r1
+    const uint32_t lastb1 = len1 ? (uint32_t)(span1 < (uint64_t)(len1 - 1u) ? span1 : (uint64_t)(len1 - 1u)) : 0u;
+    const uint64_t wend = woff[r1] + (len1 ? (lastb1 >> 5) + 1u : 0u);
+    const uint64_t nr = r1 - r0 + 1;
+    const bool fast = nr <= (uint64_t)max_reads && wend >= wbase && wend - wbase <= (uint64_t)max_words;
+    RdTile T;
+    T.wbase = wbase;
+    T.r0 = (uint32_t)r0;
+    T.nr = (uint32_t)nr;
+    T.wspan = fast ? (uint32_t)(wend - wbase) : 0xFFFFFFFFu;
+    T.pad = 0;
+    out[t] = T;
 }
 
 // Tile -> (segment, range).  Level 1: tile t covers records [t*TILE, ...).  Level 2: tiles never
@@ -575,20 +609,12 @@ __global__ __launch_bounds__(HIST_ONLY ? kRdHistThreads : kRdThreads) void k_par
     const uint64_t c0 = (uint64_t)tile * NT;  // first chunk of the tile
     const uint64_t left = S.n_chunks - c0;
     const uint32_t nch = left < (uint64_t)NT ? (uint32_t)left : (uint32_t)NT;
-    const uint32_t r0 = S.tile_read[tile], r1 = S.tile_read[tile + 1];
-    const uint32_t nr = r1 - r0 + 1;  // reads r0..r1 inclusive
-
-    // staged word window: from the word of the first base this tile touches in r0 (one base before the
-    // chunk for the incoming-edge bit) to the last word it can touch in r1
-    const uint32_t p0 = (uint32_t)(c0 - S.coff[r0]) * CH;
-    const uint64_t w_r0 = S.woff[r0], w_r1 = S.woff[r1];
-    const uint64_t wbase = w_r0 + ((p0 ? p0 - 1u : 0u) >> 5);
-    const uint32_t len1 = S.len[r1];
-    const uint64_t span1 = (c0 + NT - S.coff[r1]) * CH + k_;  // base index the tile can reach in r1
-    const uint32_t lastb1 = len1 ? (uint32_t)(span1 < (uint64_t)(len1 - 1u) ? span1 : (uint64_t)(len1 - 1u)) : 0u;
-    const uint64_t wend = w_r1 + (len1 ? (lastb1 >> 5) + 1u : 0u);
-    bool fast = nr <= (uint32_t)kRdSlots && wend >= wbase && wend - wbase <= (uint64_t)kRdWords;
-    const uint32_t wspan = fast ? (uint32_t)(wend - wbase) : 0u;
+    const RdTile T = S.tiles[tile];
+    const uint32_t r0 = T.r0, nr = T.nr;  // reads r0 .. r0+nr-1
+    const uint64_t wbase = T.wbase;
+    bool fast = T.wspan != 0xFFFFFFFFu;
+    const uint32_t wspan = fast ? T.wspan : 0u;
+    const uint64_t wend = wbase + wspan;
     if (fast) {
         bool bad = false;
         for (uint32_t i = tid; i <= nr; i += NT) {
@@ -1220,6 +1246,7 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
             h ^= h >> 14;
             h *= 0x9E3779B1u;
             uint32_t slot = (h >> 19) & (kHashSlots - 1);
+            // (probing all records of a lane in rounds, 12 ds_cmpst in flight, was measured 15 % slower)
             for (;;) {
                 const unsigned long long old = atomicCAS(&tab[slot], EMPTY, (unsigned long long)kk[i]);
                 if (old == EMPTY || old == kk[i]) break;
@@ -1652,22 +1679,26 @@ struct MsdRunner {
         const uint32_t ntiles1 = from_reads ? (uint32_t)((n_chunks + kRdThreads - 1) / kRdThreads)
                                             : (uint32_t)((Ntot + kPartTileK - 1) / kPartTileK);
         const uint32_t ntiles1h = (uint32_t)((n_chunks + kRdHistThreads - 1) / kRdHistThreads);
-        DevBuf tile_read_h;
+        DevBuf tiles_h;
         ReadSrc S{}, Sh{};
         if (from_reads) {
-            tile_read.alloc(((size_t)ntiles1 + 2) * sizeof(uint32_t));
-            tile_read_h.alloc(((size_t)ntiles1h + 2) * sizeof(uint32_t));
-            hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1 + 1 + 255) / 256), dim3(256), 0, ctx->stream,
-                               coff.as<uint64_t>(), rd->n, (uint64_t)ntiles1, (uint32_t)kRdThreads,
-                               tile_read.as<uint32_t>());
-            hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1h + 1 + 255) / 256), dim3(256), 0, ctx->stream,
-                               coff.as<uint64_t>(), rd->n, (uint64_t)ntiles1h, (uint32_t)kRdHistThreads,
-                               tile_read_h.as<uint32_t>());
-            check_launch("k_tile_reads");
-            S = ReadSrc{rd->d_words, rd->d_woff, rd->d_len, coff.as<uint64_t>(), tile_read.as<uint32_t>(), rd->n, n_chunks,
+            tile_read.alloc(((size_t)ntiles1 + 1) * sizeof(RdTile));
+            tiles_h.alloc(((size_t)ntiles1h + 1) * sizeof(RdTile));
+            if (ntiles1) {
+                hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1 + 255) / 256), dim3(256), 0, ctx->stream, coff.as<uint64_t>(),
+                                   rd->d_woff, rd->d_len, rd->n, (uint64_t)ntiles1, (uint32_t)kRdThreads,
+                                   (uint32_t)RdCfg<W>::CH, k, (uint32_t)kRdSlots, (uint32_t)kRdWords,
+                                   tile_read.as<RdTile>());
+                hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1h + 255) / 256), dim3(256), 0, ctx->stream,
+                                   coff.as<uint64_t>(), rd->d_woff, rd->d_len, rd->n, (uint64_t)ntiles1h,
+                                   (uint32_t)kRdHistThreads, (uint32_t)RdCfg<W>::CH, k, (uint32_t)kRdSlots,
+                                   (uint32_t)kRdWords, tiles_h.as<RdTile>());
+                check_launch("k_tile_reads");
+            }
+            S = ReadSrc{rd->d_words, rd->d_woff, rd->d_len, coff.as<uint64_t>(), tile_read.as<RdTile>(), rd->n, n_chunks,
                         (int)k};
             Sh = S;
-            Sh.tile_read = tile_read_h.as<uint32_t>();
+            Sh.tiles = tiles_h.as<RdTile>();
         }
         TileMap M1{nullptr, nullptr, 1, Ntot, 0, 1, nullptr};
 
