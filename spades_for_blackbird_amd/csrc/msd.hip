@@ -89,6 +89,13 @@ struct PartLevel {
     // (sel_bits bits) take part; the remaining prefix bits drive the bins
     int sel_bits;
     uint32_t sel_val;
+    // slot mode (histogram-free HASH path): bin g of this level owns the fixed range [g*slot_cap, (g+1)*slot_cap) of
+    // the output and `cursor[g]` starts at g*slot_cap; records that do not fit are appended to the spill list
+    uint32_t slot_cap;     // 0: dense layout from an exact histogram
+    void *spill_keys;      // Key<W>[spill_cap]
+    uint32_t *spill_vals;  // payloads alongside (records with a payload)
+    uint32_t *spill_count; // records appended (may run past spill_cap: the host checks)
+    uint32_t spill_cap;
 };
 
 // applies the range selection: false = the record belongs to another pass; p loses the selection bits
@@ -182,6 +189,7 @@ __global__ void k_tile_reads(const uint64_t *__restrict__ coff, const uint64_t *
 struct TileMap {
     const uint32_t *seg_tile_start;  // null for level 1
     const uint32_t *seg_off;         // record offset of every level-1 bin (nb1 + 1), level 2 only
+    const uint32_t *seg_size;        // records of every level-1 bin; null: seg_off[s + 1] - seg_off[s] (dense)
     uint32_t nseg;
     uint64_t n;
     uint32_t ntiles;  // tiles of the level
@@ -202,7 +210,7 @@ __global__ void k_tile_desc(TileMap M, const uint32_t *__restrict__ seg_nb2, con
         else hi = mid;
     }
     const uint32_t b = M.seg_off[lo] + (t - M.seg_tile_start[lo]) * tile_size;
-    const uint32_t e = M.seg_off[lo + 1];
+    const uint32_t e = M.seg_size ? M.seg_off[lo] + M.seg_size[lo] : M.seg_off[lo + 1];
     desc[t] = make_uint4(b, (e - b) < tile_size ? (e - b) : tile_size, seg_nb2[lo], seg_bin_start[lo]);
 }
 
@@ -334,8 +342,17 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
             (void)select_prefix(pfx, L);
             const uint32_t b = bin_of(pfx, L, nb);
             const uint32_t g = goff[b] + pos;
-            key_store<W>(&out[g], key);
-            if (HAS_VAL) vout[g] = vstage[pos];
+            if (L.slot_cap && (uint64_t)g >= (gbin0 + b + 1) * (uint64_t)L.slot_cap) {
+                // the bin's slot is full (a k-mer repeated far beyond the coverage, a crowded bucket): spill
+                const uint32_t sp = atomicAdd(L.spill_count, 1u);
+                if (sp < L.spill_cap) {
+                    key_store<W>(&reinterpret_cast<Key<W> *>(L.spill_keys)[sp], key);
+                    if (HAS_VAL) L.spill_vals[sp] = vstage[pos];
+                }
+            } else {
+                key_store<W>(&out[g], key);
+                if (HAS_VAL) vout[g] = vstage[pos];
+            }
         }
     }
     BBK_PH(prof_kind, 4, t_prev);  // store issue
@@ -714,7 +731,24 @@ struct BucketArgs {
     const uint32_t *bucket_ids;  // null: bucket = blockIdx.x; else the list of buckets to process
     int k;
     uint32_t *dbg;               // optional counters (BBK_VERBOSE): [0] buckets that took the all-words fallback
+    // slot mode: bucket b lies at [b*slot_cap, b*slot_cap + min(reserved, slot_cap)), reserved = cursor[b] - b*slot_cap;
+    // a bucket that reserved more than its slot is left alone (dcount = 0xFFFFFFFF): the host reprocesses it together
+    // with the spill list
+    uint32_t slot_cap;
+    const uint32_t *cursor;
 };
+
+// first record and record count of bucket b (count 0xFFFFFFFF: the slot overflowed)
+__device__ inline void bucket_range(const BucketArgs &A, uint32_t b, uint32_t *start, uint32_t *n) {
+    if (A.slot_cap) {
+        *start = b * A.slot_cap;
+        const uint32_t reserved = A.cursor[b] - *start;
+        *n = reserved > A.slot_cap ? 0xFFFFFFFFu : reserved;
+    } else {
+        *start = A.boff[b];
+        *n = A.boff[b + 1] - *start;
+    }
+}
 
 // OP: 0 unique only, 1 COUNT (run length), 2 SUM of vals, 3 OR of vals.  NT threads, CAP = NT * ITEMS.
 // Heads + segmented reduce of a bucket that lies sorted in LDS (skeys[0, n), svals alongside when the records
@@ -824,8 +858,8 @@ __global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t b = A.bucket_ids ? A.bucket_ids[blockIdx.x] : blockIdx.x;
-    const uint32_t start = A.boff[b];
-    const uint32_t n = A.boff[b + 1] - start;
+    uint32_t start, n;
+    bucket_range(A, b, &start, &n);
     if (n == 0) {
         if (tid == 0) A.dcount[b] = 0;
         return;
@@ -1034,8 +1068,8 @@ __global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, ui
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t b = A.bucket_ids ? A.bucket_ids[blockIdx.x] : blockIdx.x;
-    const uint32_t start = A.boff[b];
-    const uint32_t n = A.boff[b + 1] - start;
+    uint32_t start, n;
+    bucket_range(A, b, &start, &n);
     if (n == 0) {
         if (tid == 0) A.dcount[b] = 0;
         return;
@@ -1208,8 +1242,8 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
     uint32_t *scan_tmp = pay + (OP != 0 ? kHashSlots : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t b = A.bucket_ids ? A.bucket_ids[blockIdx.x] : blockIdx.x;
-    const uint32_t start = A.boff[b];
-    const uint32_t n = A.boff[b + 1] - start;
+    uint32_t start, n;
+    bucket_range(A, b, &start, &n);
     if (n == 0) {
         if (tid == 0) A.dcount[b] = 0;
         return;
@@ -1309,8 +1343,8 @@ __global__ __launch_bounds__(kHashIdxThreads) void k_bucket_hashidx(Key<W> *__re
     Key<W> *skeys = reinterpret_cast<Key<W> *>(scan_tmp + 32);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t b = A.bucket_ids ? A.bucket_ids[blockIdx.x] : blockIdx.x;
-    const uint32_t start = A.boff[b];
-    const uint32_t n = A.boff[b + 1] - start;
+    uint32_t start, n;
+    bucket_range(A, b, &start, &n);
     if (n == 0) {
         if (tid == 0) A.dcount[b] = 0;
         return;
@@ -1408,12 +1442,14 @@ __global__ __launch_bounds__(256) void k_compact(const Key<W> *__restrict__ buf,
                                                 const uint32_t *__restrict__ boff, const uint32_t *__restrict__ dcount,
                                                 const uint64_t *__restrict__ doff, uint32_t nbuckets,
                                                 Key<W> *__restrict__ out, uint32_t *__restrict__ vout,
-                                                uint64_t mask0) {  // cleared from word 0 (sort tag), else ~0
+                                                uint64_t mask0,  // cleared from word 0 (sort tag), else ~0
+                                                uint32_t slot_cap) {  // boff == null: bucket b starts at b*slot_cap
     const uint32_t b = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (b >= nbuckets) return;
     const int lane = threadIdx.x & 63;
-    const uint32_t c = dcount[b];
-    const uint32_t s = boff[b];
+    uint32_t c = dcount[b];
+    if (c == 0xFFFFFFFFu) c = 0;  // left to the caller (reprocessed with the spill list)
+    const uint32_t s = boff ? boff[b] : b * slot_cap;
     const uint64_t d = doff[b];
     for (uint32_t i = lane; i < c; i += 64) {
         Key<W> key = key_load<W>(&buf[s + i]);
@@ -1421,6 +1457,11 @@ __global__ __launch_bounds__(256) void k_compact(const Key<W> *__restrict__ buf,
         key_store<W>(&out[d + i], key);
         if (HAS_VAL) vout[d + i] = vals[s + i];
     }
+}
+
+__global__ void k_iota_mul(uint32_t *__restrict__ out, uint32_t n, uint32_t mul) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i * mul;
 }
 
 __global__ void k_u32_to_u64(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out, uint32_t clampv) {
@@ -1480,6 +1521,7 @@ struct MsdRunner {
     int op;        // MSD_OP_*
     bool in_vals;  // records carry a payload from the start (mask extraction or input counts)
     uint64_t strip_mask = ~0ull;  // tagged sort: bits of word 0 that survive in the output
+    bool slots_ok = getenv("BBK_NO_SLOTS") == nullptr;  // histogram-free slot mode allowed (HASH prefix)
 
     template <bool HAS_VAL, bool HIST>
     void launch_part(const char *fam, double bytes, uint32_t ntiles, const Key<W> *in, const uint32_t *vin, TileMap M,
@@ -1700,53 +1742,77 @@ struct MsdRunner {
             Sh = S;
             Sh.tiles = tiles_h.as<RdTile>();
         }
-        TileMap M1{nullptr, nullptr, 1, Ntot, 0, 1, nullptr};
+        TileMap M1{nullptr, nullptr, nullptr, 1, Ntot, 0, 1, nullptr};
 
-        // ---- level 1: histogram, offsets, scatter
+        // ---- slot mode (HASH prefix + LDS hash dedup): no histogram passes.  The hash spreads the records evenly,
+        // so every level-1 segment gets a fixed slot of the mean size + 1 % and every bucket a slot of the dedup
+        // kernel's capacity; the scatter kernels reserve space with the same per-(tile, bin) atomics, records
+        // that do not fit their slot go to a spill list, and whatever overflowed (spill list + the contents of the
+        // overflowing segments / buckets, i.e. every record of the affected keys) is reprocessed by the exact path
+        // below on a key array.  Heavy repeats therefore cost a second pass over a small part of the data.
+        const char *smin = getenv("BBK_SLOTS_MIN");  // tests lower it to run the slot mode on small inputs
+        const uint64_t slots_min = smin ? strtoull(smin, nullptr, 10) : (1ull << 22);
+        const bool slots = slots_ok && dmode == MSD_HASH && (use_hash_dedup() || use_hashidx_dedup()) && nb1 > 1 &&
+                           N >= slots_min && (double)N / kBucketFill * 1.1 + (double)N < 4.2e9;  // u32 slot offsets
+        const uint32_t seg_cap = slots ? (uint32_t)((double)N / nb1 * 1.01) + 8192u : 0u;
+        const uint32_t cap2 = bucket_cap();
+        DevBuf spill_k, spill_v, spill_n;
+        const uint32_t spill_cap = slots ? (uint32_t)(N / 8 + 65536) : 0u;
+        if (slots) {
+            spill_k.alloc((size_t)spill_cap * rec);
+            if (has_val) spill_v.alloc((size_t)spill_cap * 4);
+            spill_n.alloc(16);
+            BBK_HIP(hipMemsetAsync(spill_n.p, 0, 16, ctx->stream));
+            L1.slot_cap = seg_cap;
+            L1.spill_keys = spill_k.p;
+            L1.spill_vals = spill_v.as<uint32_t>();
+            L1.spill_count = spill_n.as<uint32_t>();
+            L1.spill_cap = spill_cap;
+        }
+
+        // ---- level 1: histogram (exact mode), offsets, scatter
         DevBuf hist1((size_t)nb1 * 4 + 16), cur1((size_t)nb1 * 4 + 16);
-        BBK_HIP(hipMemsetAsync(hist1.p, 0, (size_t)nb1 * 4 + 16, ctx->stream));
         const Key<W> *kin = (const Key<W> *)d_keys;
-        if (nb1 > 1 || sel_bits) {
-            const double hb = from_reads ? (double)rd->n_words * 8 : (double)N * rec;
-            if (from_reads) {
-                launch_part_reads<false, true>("part_hist1_reads", hb, ntiles1h, Sh, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+        std::vector<uint32_t> h1(nb1), off1(nb1 + 1), tstart(nb1 + 1), snb2(nb1), sbin(nb1 + 1);
+        std::vector<uint32_t> over_seg;  // slot mode: segments that ran over (reprocessed as a whole)
+        if (!slots) {
+            BBK_HIP(hipMemsetAsync(hist1.p, 0, (size_t)nb1 * 4 + 16, ctx->stream));
+            if (nb1 > 1 || sel_bits) {
+                const double hb = from_reads ? (double)rd->n_words * 8 : (double)N * rec;
+                if (from_reads) {
+                    launch_part_reads<false, true>("part_hist1_reads", hb, ntiles1h, Sh, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+                } else {
+                    launch_part<false, true>("part_hist1_keys", hb, ntiles1, kin, nullptr, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+                }
             } else {
-                launch_part<false, true>("part_hist1_keys", hb, ntiles1, kin, nullptr, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+                const uint32_t n32 = (uint32_t)N;
+                BBK_HIP(hipMemcpyAsync(hist1.p, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
+            }
+            BBK_HIP(hipMemcpyAsync(h1.data(), hist1.p, (size_t)nb1 * 4, hipMemcpyDeviceToHost, ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+            off1[0] = 0;
+            for (uint32_t b = 0; b < nb1; ++b) off1[b + 1] = off1[b] + h1[b];
+            if (sel_bits) {
+                N = off1[nb1];  // the records of this hash range
+                out.instances = N;
+            }
+            BBK_REQUIRE(off1[nb1] == (uint32_t)N, BBK_ERR_INTERNAL, "level-1 histogram does not add up (%u vs %llu)",
+                        off1[nb1], (unsigned long long)N);
+            if (N == 0) {
+                out.keys.alloc(16);
+                out.vals.alloc(16);
+                return 1;
             }
         } else {
-            const uint32_t n32 = (uint32_t)N;
-            BBK_HIP(hipMemcpyAsync(hist1.p, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
-        }
-        std::vector<uint32_t> h1(nb1), off1(nb1 + 1), tstart(nb1 + 1), snb2(nb1), sbin(nb1 + 1);
-        BBK_HIP(hipMemcpyAsync(h1.data(), hist1.p, (size_t)nb1 * 4, hipMemcpyDeviceToHost, ctx->stream));
-        BBK_HIP(hipStreamSynchronize(ctx->stream));
-        off1[0] = 0;
-        tstart[0] = 0;
-        sbin[0] = 0;
-        for (uint32_t b = 0; b < nb1; ++b) {
-            off1[b + 1] = off1[b] + h1[b];
-            tstart[b + 1] = tstart[b] + (h1[b] + kPartTileK - 1) / kPartTileK;
-            snb2[b] = (uint32_t)std::min<double>(kMaxBins, std::max(1.0, std::ceil((double)h1[b] / target)));
-            sbin[b + 1] = sbin[b] + snb2[b];
-        }
-        const uint32_t nbuckets = sbin[nb1];
-        if (sel_bits) {
-            N = off1[nb1];  // the records of this hash range
-            out.instances = N;
-        }
-        BBK_REQUIRE(off1[nb1] == (uint32_t)N, BBK_ERR_INTERNAL, "level-1 histogram does not add up (%u vs %llu)",
-                    off1[nb1], (unsigned long long)N);
-        if (N == 0) {
-            out.keys.alloc(16);
-            out.vals.alloc(16);
-            return 1;
+            BBK_REQUIRE((uint64_t)nb1 * seg_cap + N < (1ull << 32), BBK_ERR_INTERNAL, "slot layout exceeds 32-bit offsets");
+            for (uint32_t b = 0; b <= nb1; ++b) off1[b] = b * seg_cap;
         }
         BBK_HIP(hipMemcpyAsync(cur1.p, off1.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
 
-        DevBuf bufA(N * rec), bufB(N * rec), valA, valB;
+        const uint64_t nA = slots ? (uint64_t)nb1 * seg_cap : N;  // records bufA holds (slot layout has gaps)
+        DevBuf bufA(nA * rec), bufB, valA, valB;
         const bool need_vbuf = has_val || op != MSD_OP_NONE;
-        if (has_val) valA.alloc(N * 4);
-        if (need_vbuf) valB.alloc(N * 4);
+        if (has_val) valA.alloc(nA * 4);
         {
             const double pb = (from_reads ? (double)rd->n_words * 8 : (double)N * (rec + (has_val ? 4 : 0))) +
                               (double)N * (rec + (has_val ? 4 : 0));
@@ -1758,17 +1824,54 @@ struct MsdRunner {
                 else launch_part<false, false>("part_scatter1_keys", pb, ntiles1, kin, nullptr, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
             }
         }
+        if (slots) {
+            // the cursors tell what every segment received
+            std::vector<uint32_t> c1(nb1);
+            BBK_HIP(hipMemcpyAsync(c1.data(), cur1.p, (size_t)nb1 * 4, hipMemcpyDeviceToHost, ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+            uint64_t got = 0;
+            for (uint32_t b = 0; b < nb1; ++b) {
+                const uint32_t reserved = c1[b] - off1[b];
+                got += reserved;
+                if (reserved > seg_cap) {
+                    over_seg.push_back(b);
+                    h1[b] = 0;  // kept out of level 2
+                } else {
+                    h1[b] = reserved;
+                }
+            }
+            if (sel_bits) {
+                N = got;
+                out.instances = N;
+            }
+            BBK_REQUIRE(got == N, BBK_ERR_INTERNAL, "level-1 reservations do not add up (%llu vs %llu)",
+                        (unsigned long long)got, (unsigned long long)N);
+            if (N == 0) {
+                out.keys.alloc(16);
+                out.vals.alloc(16);
+                return 1;
+            }
+        }
+        tstart[0] = 0;
+        sbin[0] = 0;
+        for (uint32_t b = 0; b < nb1; ++b) {
+            tstart[b + 1] = tstart[b] + (h1[b] + kPartTileK - 1) / kPartTileK;
+            snb2[b] = (uint32_t)std::min<double>(kMaxBins, std::max(1.0, std::ceil((double)h1[b] / target)));
+            sbin[b + 1] = sbin[b] + snb2[b];
+        }
+        const uint32_t nbuckets = sbin[nb1];
 
         // ---- level 2
         DevBuf seg_tile(((size_t)nb1 + 1) * 4), seg_off(((size_t)nb1 + 1) * 4), seg_nb2((size_t)nb1 * 4 + 16),
-            seg_bin(((size_t)nb1 + 1) * 4);
+            seg_bin(((size_t)nb1 + 1) * 4), seg_size((size_t)nb1 * 4 + 16);
         BBK_HIP(hipMemcpyAsync(seg_tile.p, tstart.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(seg_off.p, off1.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(seg_nb2.p, snb2.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(seg_bin.p, sbin.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(seg_size.p, h1.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
         PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), sel_bits, sel_val};
         const uint32_t ntiles2 = tstart[nb1];
-        TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), nb1, N, ntiles2, 1, nullptr};
+        TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), seg_size.as<uint32_t>(), nb1, N, ntiles2, 1, nullptr};
         DevBuf desc2((size_t)ntiles2 * sizeof(uint4) + 16);
         if (ntiles2) {
             hipLaunchKernelGGL(k_tile_desc, dim3((ntiles2 + 255) / 256), dim3(256), 0, ctx->stream, M2, seg_nb2.as<uint32_t>(),
@@ -1777,10 +1880,14 @@ struct MsdRunner {
         }
         M2.desc = desc2.as<uint4>();
         DevBuf hist2((size_t)nbuckets * 4 + 16), boff(((size_t)nbuckets + 1) * 4 + 16);
-        BBK_HIP(hipMemsetAsync(hist2.p, 0, (size_t)nbuckets * 4 + 16, ctx->stream));
-        launch_part<false, true>("part_hist2", (double)N * rec, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2,
-                                 hist2.as<uint32_t>(), nullptr, nullptr, nullptr);
-        {
+        const uint64_t nB = slots ? (uint64_t)nbuckets * cap2 : N;
+        if (slots) BBK_REQUIRE(nB + N < (1ull << 32), BBK_ERR_INTERNAL, "slot layout exceeds 32-bit offsets");
+        bufB.alloc(nB * rec);
+        if (need_vbuf) valB.alloc(nB * 4);
+        if (!slots) {
+            BBK_HIP(hipMemsetAsync(hist2.p, 0, (size_t)nbuckets * 4 + 16, ctx->stream));
+            launch_part<false, true>("part_hist2", (double)N * rec, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2,
+                                     hist2.as<uint32_t>(), nullptr, nullptr, nullptr);
             DevBuf h64(((size_t)nbuckets + 1) * 8);
             hipLaunchKernelGGL(k_u32_to_u64, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream,
                                hist2.as<uint32_t>(), (uint64_t)nbuckets, h64.as<uint64_t>(), 0u);
@@ -1792,119 +1899,191 @@ struct MsdRunner {
             check_launch("k_scan_to_u32");
             BBK_HIP(hipMemcpyAsync(hist2.p, boff.p, (size_t)nbuckets * 4, hipMemcpyDeviceToDevice, ctx->stream));
             BBK_HIP(hipStreamSynchronize(ctx->stream));
+        } else {
+            // cursor of bucket g starts at its slot
+            hipLaunchKernelGGL(k_iota_mul, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream, hist2.as<uint32_t>(),
+                               nbuckets, cap2);
+            check_launch("k_iota_mul");
+            L2.slot_cap = cap2;
+            L2.spill_keys = spill_k.p;
+            L2.spill_vals = spill_v.as<uint32_t>();
+            L2.spill_count = spill_n.as<uint32_t>();
+            L2.spill_cap = spill_cap;
         }
         {
             const double pb = 2.0 * (double)N * (rec + (has_val ? 4 : 0));
             if (has_val) launch_part<true, false>("part_scatter2", pb, ntiles2, bufA.as<Key<W>>(), valA.as<uint32_t>(), M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), valB.as<uint32_t>());
             else launch_part<false, false>("part_scatter2", pb, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), nullptr);
         }
-        bufA.release();
-        valA.release();
 
         // ---- buckets in LDS
         DevBuf dcount((size_t)nbuckets * 4 + 16);
         DevBuf dbg(64);
         BBK_HIP(hipMemsetAsync(dbg.p, 0, 64, ctx->stream));
-        BucketArgs A{boff.as<uint32_t>(), dcount.as<uint32_t>(), nullptr, (int)k, verbose ? dbg.as<uint32_t>() : nullptr};
+        BucketArgs A{boff.as<uint32_t>(), dcount.as<uint32_t>(), nullptr, (int)k, verbose ? dbg.as<uint32_t>() : nullptr,
+                     slots ? cap2 : 0u, hist2.as<uint32_t>()};
         const double bb = (double)N * (rec + (has_val ? 4 : 0));
         bucket_dispatch<false>(nbuckets, bufB.as<Key<W>>(), valB.as<uint32_t>(), A, bb);
 
-        // ---- buckets above CAP: a second pass with 512-thread workgroups (2 x CAP); what still does not
-        // fit (a k-mer repeated > 12 k times in one bucket) is finished by the LSD path, one by one
         std::vector<uint32_t> hd(nbuckets), hb(nbuckets + 1);
         BBK_HIP(hipMemcpyAsync(hd.data(), dcount.p, (size_t)nbuckets * 4, hipMemcpyDeviceToHost, ctx->stream));
-        BBK_HIP(hipMemcpyAsync(hb.data(), boff.p, ((size_t)nbuckets + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (!slots)
+            BBK_HIP(hipMemcpyAsync(hb.data(), boff.p, ((size_t)nbuckets + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        uint32_t n_spill = 0;
+        if (slots) BBK_HIP(hipMemcpyAsync(&n_spill, spill_n.p, 4, hipMemcpyDeviceToHost, ctx->stream));
         BBK_HIP(hipStreamSynchronize(ctx->stream));
-        std::vector<uint32_t> big;
-        uint64_t big_rec = 0;
-        // second chance: the ballot-ranked radix kernel with 512 threads -- buckets above the first pass's
-        // capacity (8-byte keys: 2 x CAP; wider keys: more than the 4096-record hash kernel) and buckets the
-        // distribution sort turned down for a crowded bin
-        const uint32_t cap2 = BktCfg<W>::CAP2;
-        for (uint32_t b = 0; b < nbuckets; ++b)
-            if (hd[b] == 0xFFFFFFFFu && hb[b + 1] - hb[b] <= cap2) {
-                big.push_back(b);
-                big_rec += hb[b + 1] - hb[b];
-            }
-        if (!big.empty()) {
-            DevBuf ids(big.size() * 4);
-            BBK_HIP(hipMemcpyAsync(ids.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            BucketArgs A2{boff.as<uint32_t>(), dcount.as<uint32_t>(), ids.as<uint32_t>(), (int)k, nullptr};
-            const double b2 = (double)big_rec * (rec + (has_val ? 4 : 0));
-            bucket_dispatch<true>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2,
-                                            /*allow_hash=*/false);
-            BBK_HIP(hipMemcpyAsync(hd.data(), dcount.p, (size_t)nbuckets * 4, hipMemcpyDeviceToHost, ctx->stream));
-            BBK_HIP(hipStreamSynchronize(ctx->stream));
-        }
+
+        MsdOutput extra;  // slot mode: distinct records of everything that overflowed
         uint64_t novf = 0, ovf_rec = 0;
-        for (uint32_t b = 0; b < nbuckets; ++b)
-            if (hd[b] == 0xFFFFFFFFu) {
-                ++novf;
-                ovf_rec += hb[b + 1] - hb[b];
+        if (slots) {
+            if (n_spill > spill_cap) {  // more than an eighth of the input overflowed: not an input for this mode
+                if (verbose) fprintf(stderr, "[bbk] msd slots: spill list overflow (%u), exact mode\n", n_spill);
+                return 3;
             }
-        if (verbose) {
-            uint32_t mx = 0;
-            for (uint32_t b = 0; b < nbuckets; ++b) mx = std::max(mx, hb[b + 1] - hb[b]);
-            uint32_t hdbg[2] = {0, 0};
-            BBK_HIP(hipMemcpyAsync(hdbg, dbg.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-            BBK_HIP(hipStreamSynchronize(ctx->stream));
-            fprintf(stderr, "[bbk] msd all-words-fallback buckets=%u\n", hdbg[0]);
-            fprintf(stderr, "[bbk] msd mode=%d N=%llu nb1=%u buckets=%u max_bucket=%u cap=%u big=%zu lsd=%llu (%llu rec)\n",
-                    dmode, (unsigned long long)N, nb1, nbuckets, mx, bucket_cap(), big.size(), (unsigned long long)novf,
-                    (unsigned long long)ovf_rec);
-        }
-        if (novf > 256 || ovf_rec > N / 4) return 0;
-        if (novf) {
-            const ReduceOp rop = op == MSD_OP_OR ? REDUCE_OR : (op == MSD_OP_SUM ? REDUCE_SUM : REDUCE_COUNT);
-            for (uint32_t b = 0; b < nbuckets; ++b) {
-                if (hd[b] != 0xFFFFFFFFu) continue;
-                const uint64_t cnt = hb[b + 1] - hb[b];
-                Key<W> *kb = bufB.as<Key<W>>() + hb[b];
-                uint32_t *vb = need_vbuf ? valB.as<uint32_t>() + hb[b] : nullptr;
-                DevBuf tk(cnt * rec), tv(cnt * 4), ok(cnt * rec), ov(cnt * 4);
-                sort_records(ctx, W, kb, tk.p, has_val ? vb : nullptr, has_val ? tv.as<uint32_t>() : nullptr, cnt,
-                             key_passes(k));
-                const uint64_t d = unique_records(ctx, W, kb, has_val ? vb : nullptr, cnt, ok.p,
-                                                  op != MSD_OP_NONE ? ov.as<uint32_t>() : nullptr, rop, false);
-                BBK_HIP(hipMemcpyAsync(kb, ok.p, d * rec, hipMemcpyDeviceToDevice, ctx->stream));
-                if (op != MSD_OP_NONE)
-                    BBK_HIP(hipMemcpyAsync(vb, ov.p, d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            std::vector<uint32_t> over_bkt;
+            for (uint32_t b = 0; b < nbuckets; ++b)
+                if (hd[b] == 0xFFFFFFFFu) over_bkt.push_back(b);
+            const uint64_t n_extra = (uint64_t)n_spill + (uint64_t)over_seg.size() * seg_cap + (uint64_t)over_bkt.size() * cap2;
+            if (verbose)
+                fprintf(stderr, "[bbk] msd slots N=%llu nb1=%u seg_cap=%u buckets=%u spill=%u over_seg=%zu over_bkt=%zu\n",
+                        (unsigned long long)N, nb1, seg_cap, nbuckets, n_spill, over_seg.size(), over_bkt.size());
+            if (n_extra > N / 2) {  // most of the input overflowed (a handful of distinct k-mers): not for this mode
+                if (verbose) fprintf(stderr, "[bbk] msd slots: %llu of %llu records overflowed, exact mode\n",
+                                     (unsigned long long)n_extra, (unsigned long long)N);
+                return 3;
+            }
+            if (n_extra) {
+                // every record of the affected keys: the spill list, the overflowing segments' and buckets' slots
+                DevBuf ek(n_extra * rec), ev;
+                if (has_val) ev.alloc(n_extra * 4);
+                uint64_t o = 0;
+                auto put = [&](const void *ksrc, const uint32_t *vsrc, uint64_t first, uint64_t cnt) {
+                    if (!cnt) return;
+                    BBK_HIP(hipMemcpyAsync(ek.as<char>() + o * rec, (const char *)ksrc + first * rec, cnt * rec,
+                                           hipMemcpyDeviceToDevice, ctx->stream));
+                    if (has_val)
+                        BBK_HIP(hipMemcpyAsync(ev.as<uint32_t>() + o, vsrc + first, cnt * 4, hipMemcpyDeviceToDevice,
+                                               ctx->stream));
+                    o += cnt;
+                };
+                put(spill_k.p, spill_v.as<uint32_t>(), 0, n_spill);
+                for (uint32_t b : over_seg) put(bufA.p, valA.as<uint32_t>(), (uint64_t)b * seg_cap, seg_cap);
+                for (uint32_t b : over_bkt) put(bufB.p, valB.as<uint32_t>(), (uint64_t)b * cap2, cap2);
                 BBK_HIP(hipStreamSynchronize(ctx->stream));
-                hd[b] = (uint32_t)d;
+                MsdRunner<W> exact = *this;
+                exact.slots_ok = false;
+                // declined (e.g. one k-mer makes up most of it): so does this call, the caller takes the LSD path
+                if (!exact.run_all(nullptr, ek.p, has_val ? ev.as<uint32_t>() : nullptr, n_extra, false, extra)) return 0;
+                extra.bucket_off.release();
             }
-            BBK_HIP(hipMemcpyAsync(dcount.p, hd.data(), (size_t)nbuckets * 4, hipMemcpyHostToDevice, ctx->stream));
+            novf = over_bkt.size() + over_seg.size();
+        }
+        bufA.release();
+        valA.release();
+
+        if (!slots) {
+            // ---- buckets above CAP: a second pass with 512-thread workgroups (2 x CAP); what still does not
+            // fit (a k-mer repeated > 12 k times in one bucket) is finished by the LSD path, one by one
+            std::vector<uint32_t> big;
+            uint64_t big_rec = 0;
+            // second chance: the ballot-ranked radix kernel with 512 threads -- buckets above the first pass's
+            // capacity (8-byte keys: 2 x CAP; wider keys: more than the 4096-record hash kernel) and buckets the
+            // distribution sort turned down for a crowded bin
+            const uint32_t cap2nd = BktCfg<W>::CAP2;
+            for (uint32_t b = 0; b < nbuckets; ++b)
+                if (hd[b] == 0xFFFFFFFFu && hb[b + 1] - hb[b] <= cap2nd) {
+                    big.push_back(b);
+                    big_rec += hb[b + 1] - hb[b];
+                }
+            if (!big.empty()) {
+                DevBuf ids(big.size() * 4);
+                BBK_HIP(hipMemcpyAsync(ids.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+                BucketArgs A2{boff.as<uint32_t>(), dcount.as<uint32_t>(), ids.as<uint32_t>(), (int)k, nullptr, 0u, nullptr};
+                const double b2 = (double)big_rec * (rec + (has_val ? 4 : 0));
+                bucket_dispatch<true>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2,
+                                      /*allow_hash=*/false);
+                BBK_HIP(hipMemcpyAsync(hd.data(), dcount.p, (size_t)nbuckets * 4, hipMemcpyDeviceToHost, ctx->stream));
+                BBK_HIP(hipStreamSynchronize(ctx->stream));
+            }
+            for (uint32_t b = 0; b < nbuckets; ++b)
+                if (hd[b] == 0xFFFFFFFFu) {
+                    ++novf;
+                    ovf_rec += hb[b + 1] - hb[b];
+                }
+            if (verbose) {
+                uint32_t mx = 0;
+                for (uint32_t b = 0; b < nbuckets; ++b) mx = std::max(mx, hb[b + 1] - hb[b]);
+                uint32_t hdbg[2] = {0, 0};
+                BBK_HIP(hipMemcpyAsync(hdbg, dbg.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+                BBK_HIP(hipStreamSynchronize(ctx->stream));
+                fprintf(stderr, "[bbk] msd all-words-fallback buckets=%u\n", hdbg[0]);
+                fprintf(stderr, "[bbk] msd mode=%d N=%llu nb1=%u buckets=%u max_bucket=%u cap=%u big=%zu lsd=%llu (%llu rec)\n",
+                        dmode, (unsigned long long)N, nb1, nbuckets, mx, bucket_cap(), big.size(), (unsigned long long)novf,
+                        (unsigned long long)ovf_rec);
+            }
+            if (novf > 256 || ovf_rec > N / 4) return 0;
+            if (novf) {
+                const ReduceOp rop = op == MSD_OP_OR ? REDUCE_OR : (op == MSD_OP_SUM ? REDUCE_SUM : REDUCE_COUNT);
+                for (uint32_t b = 0; b < nbuckets; ++b) {
+                    if (hd[b] != 0xFFFFFFFFu) continue;
+                    const uint64_t cnt = hb[b + 1] - hb[b];
+                    Key<W> *kb = bufB.as<Key<W>>() + hb[b];
+                    uint32_t *vb = need_vbuf ? valB.as<uint32_t>() + hb[b] : nullptr;
+                    DevBuf tk(cnt * rec), tv(cnt * 4), ok(cnt * rec), ov(cnt * 4);
+                    sort_records(ctx, W, kb, tk.p, has_val ? vb : nullptr, has_val ? tv.as<uint32_t>() : nullptr, cnt,
+                                 key_passes(k));
+                    const uint64_t d = unique_records(ctx, W, kb, has_val ? vb : nullptr, cnt, ok.p,
+                                                      op != MSD_OP_NONE ? ov.as<uint32_t>() : nullptr, rop, false);
+                    BBK_HIP(hipMemcpyAsync(kb, ok.p, d * rec, hipMemcpyDeviceToDevice, ctx->stream));
+                    if (op != MSD_OP_NONE)
+                        BBK_HIP(hipMemcpyAsync(vb, ov.p, d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                    BBK_HIP(hipStreamSynchronize(ctx->stream));
+                    hd[b] = (uint32_t)d;
+                }
+                BBK_HIP(hipMemcpyAsync(dcount.p, hd.data(), (size_t)nbuckets * 4, hipMemcpyHostToDevice, ctx->stream));
+            }
         }
         out.overflow_buckets = novf;
 
-        // ---- dense output
+        // ---- dense output (slot mode: overflowing buckets count 0 here; their records are in `extra`)
         DevBuf d64(((size_t)nbuckets + 1) * 8);
         hipLaunchKernelGGL(k_u32_to_u64, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream, dcount.as<uint32_t>(),
                            (uint64_t)nbuckets, d64.as<uint64_t>(), 0u);
         check_launch("k_u32_to_u64");
         const uint64_t D = exclusive_scan_u64(ctx, d64.as<uint64_t>(), d64.as<uint64_t>(), nbuckets);
-        out.n = D;
-        out.keys.alloc(D * rec);
+        out.n = D + extra.n;
+        out.keys.alloc(out.n * rec + 16);
         const bool out_vals = op != MSD_OP_NONE;
-        if (out_vals) out.vals.alloc(D * 4);
+        if (out_vals) out.vals.alloc(out.n * 4 + 16);
         {
             KernelTimer t(ctx, "compact", 2.0 * (double)D * (rec + (out_vals ? 4 : 0)));
             const unsigned blocks = (unsigned)(((uint64_t)nbuckets * 64 + 255) / 256);
+            const uint32_t *bo = slots ? nullptr : boff.as<uint32_t>();
             if (out_vals)
                 hipLaunchKernelGGL((k_compact<W, true>), dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<Key<W>>(),
-                                   valB.as<uint32_t>(), boff.as<uint32_t>(), dcount.as<uint32_t>(), d64.as<uint64_t>(),
-                                   nbuckets, out.keys.as<Key<W>>(), out.vals.as<uint32_t>(), strip_mask);
+                                   valB.as<uint32_t>(), bo, dcount.as<uint32_t>(), d64.as<uint64_t>(), nbuckets,
+                                   out.keys.as<Key<W>>(), out.vals.as<uint32_t>(), strip_mask, cap2);
             else
                 hipLaunchKernelGGL((k_compact<W, false>), dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<Key<W>>(),
-                                   (const uint32_t *)nullptr, boff.as<uint32_t>(), dcount.as<uint32_t>(),
-                                   d64.as<uint64_t>(), nbuckets, out.keys.as<Key<W>>(), (uint32_t *)nullptr, strip_mask);
+                                   (const uint32_t *)nullptr, bo, dcount.as<uint32_t>(), d64.as<uint64_t>(), nbuckets,
+                                   out.keys.as<Key<W>>(), (uint32_t *)nullptr, strip_mask, cap2);
             check_launch("k_compact");
         }
-        // bucket table for lookups (HASH mode): offsets of every bucket in the dense output
-        out.nbuckets = nbuckets;
-        out.bucket_off.alloc(((size_t)nbuckets + 1) * 4);
-        hipLaunchKernelGGL(k_scan_to_u32, dim3((nbuckets + 1 + 255) / 256), dim3(256), 0, ctx->stream, d64.as<uint64_t>(),
-                           (uint64_t)nbuckets, D, out.bucket_off.as<uint32_t>());
-        check_launch("k_scan_to_u32");
+        if (extra.n) {
+            BBK_HIP(hipMemcpyAsync(out.keys.as<char>() + D * rec, extra.keys.p, extra.n * rec, hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+            if (out_vals)
+                BBK_HIP(hipMemcpyAsync(out.vals.as<uint32_t>() + D, extra.vals.p, extra.n * 4, hipMemcpyDeviceToDevice,
+                                       ctx->stream));
+        }
+        // bucket table (exact HASH mode only): offsets of every bucket in the dense output
+        out.nbuckets = slots ? 0 : nbuckets;
+        if (!slots) {
+            out.bucket_off.alloc(((size_t)nbuckets + 1) * 4);
+            hipLaunchKernelGGL(k_scan_to_u32, dim3((nbuckets + 1 + 255) / 256), dim3(256), 0, ctx->stream,
+                               d64.as<uint64_t>(), (uint64_t)nbuckets, D, out.bucket_off.as<uint32_t>());
+            check_launch("k_scan_to_u32");
+        }
         BBK_HIP(hipStreamSynchronize(ctx->stream));
         return 1;
     }
@@ -1914,14 +2093,23 @@ struct MsdRunner {
     bool run_all(const bbk_reads *rd, const void *d_keys, const uint32_t *d_vals, uint64_t n_in, bool with_mask,
                  MsdOutput &out) {
         int bits = 0;
-        const int r = run(rd, d_keys, d_vals, n_in, with_mask, out, 0, 0, &bits);
+        int r = run(rd, d_keys, d_vals, n_in, with_mask, out, 0, 0, &bits);
+        if (r == 3) {  // the slot mode gave up (too much of the input overflowed its slots): exact histograms
+            slots_ok = false;
+            r = run(rd, d_keys, d_vals, n_in, with_mask, out, 0, 0, &bits);
+        }
         if (r != 2) return r == 1;
         const size_t rec = (size_t)W * 8;
         const bool out_vals = op != MSD_OP_NONE;
         std::vector<MsdOutput> parts((size_t)1 << bits);
         uint64_t D = 0, inst = 0;
         for (uint32_t v = 0; v < (1u << bits); ++v) {
-            if (run(rd, nullptr, nullptr, 0, with_mask, parts[v], bits, v, nullptr) != 1) return false;
+            int rv = run(rd, nullptr, nullptr, 0, with_mask, parts[v], bits, v, nullptr);
+            if (rv == 3) {
+                slots_ok = false;
+                rv = run(rd, nullptr, nullptr, 0, with_mask, parts[v], bits, v, nullptr);
+            }
+            if (rv != 1) return false;
             D += parts[v].n;
             inst += parts[v].instances;
             parts[v].bucket_off.release();
