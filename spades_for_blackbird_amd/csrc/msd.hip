@@ -1492,6 +1492,16 @@ __global__ __launch_bounds__(256) void k_compact(const Key<W> *__restrict__ buf,
     }
 }
 
+// ids of the buckets the first-pass kernel left alone (dcount == 0xFFFFFFFF); *count may run past cap
+__global__ void k_flagged(const uint32_t *__restrict__ dcount, uint32_t n, uint32_t *__restrict__ ids, uint32_t cap,
+                          uint32_t *__restrict__ count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && dcount[i] == 0xFFFFFFFFu) {
+        const uint32_t at = atomicAdd(count, 1u);
+        if (at < cap) ids[at] = i;
+    }
+}
+
 __global__ void k_iota_mul(uint32_t *__restrict__ out, uint32_t n, uint32_t mul) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = i * mul;
@@ -1792,7 +1802,8 @@ struct MsdRunner {
         // bucket slots 256 B further apart than their capacity: with a power-of-two-ish stride every bucket's
         // fill front sits in the same HBM channel (level-2 scatter measured 10 % slower)
         const uint32_t stride2 = cap2 + (uint32_t)(256 / rec);
-        DevBuf spill_k, spill_v, spill_n;
+        DevBuf spill_k, spill_v, spill_n;  // spill_n: u32 counters [0] spilled records [1] records written by the
+                                           // dedup kernels [2] buckets left to the caller
         const uint32_t spill_cap = slots ? (uint32_t)(N / 8 + 65536) : 0u;
         if (slots) {
             spill_k.alloc((size_t)spill_cap * rec);
@@ -1960,29 +1971,53 @@ struct MsdRunner {
         BBK_HIP(hipMemsetAsync(dbg.p, 0, 64, ctx->stream));
         // slot mode: the hash-dedup kernels write the distinct records straight into the (unordered) result
         const bool out_vals = op != MSD_OP_NONE;
-        DevBuf direct_n;
         if (slots) {
             out.keys.alloc((N + 16) * rec);  // upper bound; transient in every caller (expanded / exchanged next)
             if (out_vals) out.vals.alloc((N + 16) * 4);
-            direct_n.alloc(16);
-            BBK_HIP(hipMemsetAsync(direct_n.p, 0, 16, ctx->stream));
         }
         BucketArgs A{boff.as<uint32_t>(), dcount.as<uint32_t>(), nullptr, (int)k, verbose ? dbg.as<uint32_t>() : nullptr,
                      slots ? cap2 : 0u, slots ? stride2 : 0u, hist2.as<uint32_t>(), slots ? out.keys.p : nullptr,
-                     slots ? out.vals.as<uint32_t>() : nullptr, slots ? direct_n.as<uint32_t>() : nullptr};
+                     slots ? out.vals.as<uint32_t>() : nullptr, slots ? spill_n.as<uint32_t>() + 1 : nullptr};
         const double bb = (double)N * (rec + (has_val ? 4 : 0));
         bucket_dispatch<false>(nbuckets, bufB.as<Key<W>>(), valB.as<uint32_t>(), A, bb);
 
-        std::vector<uint32_t> hd(nbuckets), hb(nbuckets + 1);
-        BBK_HIP(hipMemcpyAsync(hd.data(), dcount.p, (size_t)nbuckets * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (!slots)
-            BBK_HIP(hipMemcpyAsync(hb.data(), boff.p, ((size_t)nbuckets + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-        uint32_t n_spill = 0, n_direct = 0;
+        // buckets the first pass left alone: listed on the device, only the (short) list comes to the host
+        constexpr uint32_t kFlagCap = 65536;
+        DevBuf flag_ids((size_t)kFlagCap * 4), flag_n;
+        uint32_t *d_flag_n = nullptr;
         if (slots) {
-            BBK_HIP(hipMemcpyAsync(&n_spill, spill_n.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-            BBK_HIP(hipMemcpyAsync(&n_direct, direct_n.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            d_flag_n = spill_n.as<uint32_t>() + 2;
+        } else {
+            flag_n.alloc(16);
+            BBK_HIP(hipMemsetAsync(flag_n.p, 0, 16, ctx->stream));
+            d_flag_n = flag_n.as<uint32_t>();
         }
+        hipLaunchKernelGGL(k_flagged, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream, dcount.as<uint32_t>(),
+                           nbuckets, flag_ids.as<uint32_t>(), kFlagCap, d_flag_n);
+        check_launch("k_flagged");
+        uint32_t ctr[4] = {0, 0, 0, 0};  // spilled, direct, flagged
+        if (slots) BBK_HIP(hipMemcpyAsync(ctr, spill_n.p, 12, hipMemcpyDeviceToHost, ctx->stream));
+        else BBK_HIP(hipMemcpyAsync(ctr + 2, flag_n.p, 4, hipMemcpyDeviceToHost, ctx->stream));
         BBK_HIP(hipStreamSynchronize(ctx->stream));
+        const uint32_t n_spill = ctr[0], n_direct = ctr[1], n_flag = ctr[2];
+        if (n_flag > kFlagCap) {  // tens of thousands of overflowing buckets: not an input for this path
+            if (verbose) fprintf(stderr, "[bbk] msd: %u buckets overflow\n", n_flag);
+            return slots ? 3 : 0;
+        }
+        std::vector<uint32_t> flagged(n_flag);
+        if (n_flag) {
+            BBK_HIP(hipMemcpyAsync(flagged.data(), flag_ids.p, (size_t)n_flag * 4, hipMemcpyDeviceToHost, ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+            std::sort(flagged.begin(), flagged.end());
+        }
+        std::vector<uint32_t> hd, hb;  // exact mode with flagged buckets (or verbose): per-bucket counts / offsets
+        if (!slots && (n_flag || verbose)) {
+            hd.resize(nbuckets);
+            hb.resize((size_t)nbuckets + 1);
+            BBK_HIP(hipMemcpyAsync(hd.data(), dcount.p, (size_t)nbuckets * 4, hipMemcpyDeviceToHost, ctx->stream));
+            BBK_HIP(hipMemcpyAsync(hb.data(), boff.p, ((size_t)nbuckets + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+        }
 
         MsdOutput extra;  // slot mode: distinct records of everything that overflowed
         uint64_t novf = 0, ovf_rec = 0;
@@ -1991,9 +2026,7 @@ struct MsdRunner {
                 if (verbose) fprintf(stderr, "[bbk] msd slots: spill list overflow (%u), exact mode\n", n_spill);
                 return 3;
             }
-            std::vector<uint32_t> over_bkt;
-            for (uint32_t b = 0; b < nbuckets; ++b)
-                if (hd[b] == 0xFFFFFFFFu) over_bkt.push_back(b);
+            const std::vector<uint32_t> &over_bkt = flagged;
             const uint64_t n_extra = (uint64_t)n_spill + (uint64_t)over_seg.size() * seg_cap + (uint64_t)over_bkt.size() * cap2;
             if (verbose)
                 fprintf(stderr, "[bbk] msd slots N=%llu nb1=%u seg_cap=%u buckets=%u spill=%u over_seg=%zu over_bkt=%zu\n",
@@ -2032,7 +2065,7 @@ struct MsdRunner {
         bufA.release();
         valA.release();
 
-        if (!slots) {
+        if (!slots && (n_flag || verbose)) {
             // ---- buckets above CAP: a second pass with 512-thread workgroups (2 x CAP); what still does not
             // fit (a k-mer repeated > 12 k times in one bucket) is finished by the LSD path, one by one
             std::vector<uint32_t> big;
