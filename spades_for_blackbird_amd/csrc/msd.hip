@@ -369,6 +369,54 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
 #endif
 }
 
+// Record of item i of a lane inside its tile.  8-byte keys: the items come in adjacent pairs, so that a full tile is
+// read with 16-byte loads (global_load_dwordx4: half the load instructions of the 8-byte striping); the order of
+// the records inside a tile is irrelevant (the scatter is unstable, the histogram a sum).
+template <int W, int THREADS>
+__device__ __forceinline__ uint32_t tile_local(int i, int tid) {
+    if (W == 1) return (uint32_t)((((i >> 1) * THREADS + tid) << 1) | (i & 1));
+    return (uint32_t)(i * THREADS + tid);
+}
+
+typedef uint64_t KeyPair __attribute__((ext_vector_type(2), aligned(8)));  // 16 bytes, 8-byte aligned
+
+// all ITEMS records of a lane; every load is issued before the first use (a load inside a `local < count` branch
+// would be waited for before the next one is issued: one memory latency per record)
+template <int W, int ITEMS, int THREADS, bool HAS_VAL>
+__device__ __forceinline__ void tile_load(const Key<W> *__restrict__ in, const uint32_t *__restrict__ vin, uint64_t begin,
+                                          uint32_t count, int tid, Key<W> (&keys)[ITEMS], uint32_t (&vals)[ITEMS]) {
+    if constexpr (W == 1) {
+        if (count == (uint32_t)(ITEMS * THREADS)) {  // full tile (uniform): pairs
+            const uint64_t *base = reinterpret_cast<const uint64_t *>(in) + begin;
+#pragma unroll
+            for (int i = 0; i < ITEMS; i += 2) {
+                const uint32_t local = tile_local<W, THREADS>(i, tid);
+                const KeyPair p = *reinterpret_cast<const KeyPair *>(base + local);
+                keys[i].w[0] = p.x;
+                keys[i + 1].w[0] = p.y;
+                vals[i] = HAS_VAL ? vin[begin + local] : 0u;
+                vals[i + 1] = HAS_VAL ? vin[begin + local + 1] : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const uint32_t local = tile_local<W, THREADS>(i, tid);
+                const uint64_t at = begin + (local < count ? local : count - 1u);  // clamped into the tile
+                keys[i] = key_load<W>(&in[at]);
+                vals[i] = HAS_VAL ? vin[at] : 0u;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t local = tile_local<W, THREADS>(i, tid);
+            const uint64_t at = begin + (local < count ? local : count - 1u);  // clamped into the tile
+            keys[i] = key_load<W>(&in[at]);
+            vals[i] = HAS_VAL ? vin[at] : 0u;
+        }
+    }
+}
+
 // One partition level over a key array.  HIST_ONLY: accumulate the level histogram; else scatter.
 // LVL1: level-1 kernels have at most 512 bins (smaller LDS tables: two workgroups per CU)
 template <int W, bool HAS_VAL, bool HIST_ONLY, bool LVL1>
@@ -413,17 +461,12 @@ __global__ __launch_bounds__(PartCfg<W>::THREADS) void k_part(const Key<W> *__re
                 for (uint32_t b = tid; b < nb; b += kPartThreads) lhist[b] = 0;
                 __syncthreads();
             }
-            // all loads first (unconditional, index clamped into the tile), then the ranking: a load inside the
-            // `local < count` branch would be waited for before the next one is issued
             Key<W> keys[kPartItems];
+            uint32_t unused[kPartItems];
+            tile_load<W, kPartItems, kPartThreads, false>(in, nullptr, begin, count, tid, keys, unused);
 #pragma unroll
             for (int i = 0; i < kPartItems; ++i) {
-                const uint32_t local = (uint32_t)(i * kPartThreads + tid);
-                keys[i] = key_load<W>(&in[begin + (local < count ? local : count - 1u)]);
-            }
-#pragma unroll
-            for (int i = 0; i < kPartItems; ++i) {
-                const uint32_t local = (uint32_t)(i * kPartThreads + tid);
+                const uint32_t local = tile_local<W, kPartThreads>(i, tid);
                 if (local < count) {
                     uint32_t pfx = prefix_of<W>(keys[i], L.dmode, L.w0bits);
                     if (select_prefix(pfx, L)) atomicAdd(&lhist[bin_of(pfx, L, nb)], 1u);
@@ -455,16 +498,7 @@ __global__ __launch_bounds__(PartCfg<W>::THREADS) void k_part(const Key<W> *__re
     Key<W> keys[kPartItems];
     uint32_t vals[kPartItems];
     uint32_t binrank[kPartItems];  // bin << 16 | rank (rank < 8192 fits 13 bits; bins < 1024)
-    // striped over the block: coalesced 8/16-byte loads.  All loads are issued first (unconditional, index
-    // clamped into the tile): a load inside the `local < count` branch would be waited for before the next
-    // one is issued, i.e. one full memory latency per record.
-#pragma unroll
-    for (int i = 0; i < kPartItems; ++i) {
-        const uint32_t local = (uint32_t)(i * kPartThreads + tid);
-        const uint64_t at = begin + (local < count ? local : count - 1u);
-        keys[i] = key_load<W>(&in[at]);
-        vals[i] = HAS_VAL ? vin[at] : 0u;
-    }
+    tile_load<W, kPartItems, kPartThreads, HAS_VAL>(in, vin, begin, count, tid, keys, vals);
     // keep the records in registers: otherwise hipcc re-loads them from (restrict, read-only) memory for the LDS
     // reorder, which doubles the L2 traffic and, vmcnt being in-order, puts the reservation atomics issued in
     // between back on the critical path
@@ -476,7 +510,7 @@ __global__ __launch_bounds__(PartCfg<W>::THREADS) void k_part(const Key<W> *__re
     }
 #pragma unroll
     for (int i = 0; i < kPartItems; ++i) {
-        const uint32_t local = (uint32_t)(i * kPartThreads + tid);
+        const uint32_t local = tile_local<W, kPartThreads>(i, tid);
         binrank[i] = 0xFFFFFFFFu;
         if (local < count) {
             uint32_t pfx = prefix_of<W>(keys[i], L.dmode, L.w0bits);
