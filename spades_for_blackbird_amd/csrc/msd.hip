@@ -242,7 +242,7 @@ __device__ inline TileInfo tile_info(const TileMap &M, const PartLevel &L, uint3
 #ifdef BBK_PHASE_PROF
 // phase clocks of the scatter kernels (diagnostic build only): [kernel kind][phase] summed shader cycles of
 // thread 0 of every workgroup, [..][7] = workgroups
-__device__ unsigned long long g_phase[4][8];
+__device__ unsigned long long g_phase[6][8];
 #define BBK_PH(kind, ph, t_prev)                                                   \
     do {                                                                           \
         if (threadIdx.x == 0) {                                                    \
@@ -1126,6 +1126,9 @@ __global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, ui
         return;
     }
     for (uint32_t q = tid; q < (uint32_t)kDistBins; q += NT) bins[q] = 0;
+#ifdef BBK_PHASE_PROF
+    unsigned long long t_prev = clock64();
+#endif
 
     // records of this thread (striped over the bucket); all loads issued before the first use
     Key<W> keys[ITEMS];
@@ -1162,6 +1165,7 @@ __global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, ui
         mn = mm[2 * j] < mn ? mm[2 * j] : mn;
         mx = mm[2 * j + 1] > mx ? mm[2 * j + 1] : mx;
     }
+    BBK_PH(3, 0, t_prev);  // loads + min/max
     const uint64_t kmin = mn;
     const int rbits = 64 - __builtin_clzll((mx - mn) | 1ull);
     const int sh = rbits > 12 ? rbits - 12 : 0;  // digit = (word 0 - min) >> sh < 4096
@@ -1172,6 +1176,7 @@ __global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, ui
         if (p < n) atomicAdd(&bins[(uint32_t)((keys[i].w[0] - kmin) >> sh)], 1u);
     }
     __syncthreads();
+    BBK_PH(3, 1, t_prev);  // count
     // exclusive scan of the bins; thread t owns bins [t*BPT, (t+1)*BPT)
     uint32_t c[BPT];
     uint32_t sum = 0;
@@ -1204,6 +1209,7 @@ __global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, ui
         }
     }
     __syncthreads();
+    BBK_PH(3, 2, t_prev);  // scan
     uint32_t pos_of[ITEMS];  // where the scatter put the record (breaks ties between equal keys)
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -1216,37 +1222,101 @@ __global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, ui
         }
     }
     __syncthreads();
+    BBK_PH(3, 3, t_prev);  // scatter
     // order inside the bins, record-parallel: a record's final place is its bin's start plus the number of
     // records of the bin that go before it (smaller key; equal key: scattered to a lower position).  After the
     // scatter bins[d] is the END of bin d, so bin d = [bins[d-1], bins[d]).
+    // Batched so that the LDS reads of several records are in flight together (one record at a time is three
+    // dependent LDS round trips: bin bounds, candidates, compare): RB records per round, the first four candidates
+    // of every bin read unconditionally; the rare fuller bins finish in a loop.
     uint32_t dest[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t p = (uint32_t)(i * NT + tid);
-        dest[i] = 0xFFFFFFFFu;
-        if (p < n) {
-            const uint32_t d = (uint32_t)((keys[i].w[0] - kmin) >> sh);
-            const uint32_t sb = d ? bins[d - 1] : 0u, e = bins[d];
-            uint32_t before = 0;
-            if (e - sb > 1) {
-                for (uint32_t y = sb; y < e; y += 4) {  // four candidates in flight per round
-                    Key<W> o[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) o[u] = key_load<W>(&skeys[y + u < e ? y + u : e - 1]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (y + u < e) {
-                            const bool lt = key_less_words<W>(o[u], keys[i]);
-                            const bool eq = key_eq<W>(o[u], keys[i]);
-                            before += (lt || (eq && y + u < pos_of[i])) ? 1u : 0u;
-                        }
+    if constexpr (W == 1) {
+        constexpr int RB = 6;
+    #pragma unroll
+        for (int i0 = 0; i0 < ITEMS; i0 += RB) {
+            uint32_t sb[RB], e[RB];
+    #pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int i = i0 + u;
+                sb[u] = e[u] = 0;
+                if (i < ITEMS) {
+                    const uint32_t p = (uint32_t)(i * NT + tid);
+                    if (p < n) {
+                        const uint32_t d = (uint32_t)((keys[i].w[0] - kmin) >> sh);
+                        sb[u] = d ? bins[d - 1] : 0u;
+                        e[u] = bins[d];
                     }
                 }
             }
-            dest[i] = sb + before;
+            Key<W> o[RB][4];
+    #pragma unroll
+            for (int u = 0; u < RB; ++u) {
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t y = sb[u] + c;
+                    o[u][c] = key_load<W>(&skeys[y < e[u] ? y : (e[u] ? e[u] - 1u : 0u)]);
+                }
+            }
+    #pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int i = i0 + u;
+                if (i < ITEMS) {
+                    dest[i] = 0xFFFFFFFFu;
+                    const uint32_t p = (uint32_t)(i * NT + tid);
+                    if (p < n) {
+                        uint32_t before = 0;
+    #pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t y = sb[u] + c;
+                            if (y < e[u]) {
+                                const bool lt = key_less_words<W>(o[u][c], keys[i]);
+                                const bool eq = key_eq<W>(o[u][c], keys[i]);
+                                before += (lt || (eq && y < pos_of[i])) ? 1u : 0u;
+                            }
+                        }
+                        for (uint32_t y = sb[u] + 4; y < e[u]; ++y) {  // bins above four records
+                            const Key<W> ok = key_load<W>(&skeys[y]);
+                            const bool lt = key_less_words<W>(ok, keys[i]);
+                            const bool eq = key_eq<W>(ok, keys[i]);
+                            before += (lt || (eq && y < pos_of[i])) ? 1u : 0u;
+                        }
+                        dest[i] = sb[u] + before;
+                    }
+                }
+            }
+        }
+    } else {
+        // wider keys: one record at a time, four candidates in flight (the batched form costs more registers than
+        // it saves: measured 8 % slower for 16-byte keys)
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t p = (uint32_t)(i * NT + tid);
+            dest[i] = 0xFFFFFFFFu;
+            if (p < n) {
+                const uint32_t d = (uint32_t)((keys[i].w[0] - kmin) >> sh);
+                const uint32_t sb = d ? bins[d - 1] : 0u, e = bins[d];
+                uint32_t before = 0;
+                if (e - sb > 1) {
+                    for (uint32_t y = sb; y < e; y += 4) {
+                        Key<W> o[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) o[u] = key_load<W>(&skeys[y + u < e ? y + u : e - 1]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (y + u < e) {
+                                const bool lt = key_less_words<W>(o[u], keys[i]);
+                                const bool eq = key_eq<W>(o[u], keys[i]);
+                                before += (lt || (eq && y + u < pos_of[i])) ? 1u : 0u;
+                            }
+                        }
+                    }
+                }
+                dest[i] = sb + before;
+            }
         }
     }
     __syncthreads();  // every rank is computed from the scattered order: only now overwrite it
+    BBK_PH(3, 4, t_prev);  // rank
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         if (dest[i] != 0xFFFFFFFFu) {
@@ -1255,7 +1325,12 @@ __global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, ui
         }
     }
     __syncthreads();
+    BBK_PH(3, 5, t_prev);  // write
     bucket_reduce<W, NT, ITEMS, OP>(skeys, svals, scan_tmp, n, start, b, buf, vals, A);
+    BBK_PH(3, 6, t_prev);  // heads + reduce + output
+#ifdef BBK_PHASE_PROF
+    if (threadIdx.x == 0) atomicAdd(&g_phase[3][7], 1ull);
+#endif
 }
 
 template <int W, int NT, int ITEMS, int OP>
@@ -1300,11 +1375,15 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
         return;
     }
     constexpr unsigned long long EMPTY = ~0ull;
+#ifdef BBK_PHASE_PROF
+    unsigned long long t_prev = clock64();
+#endif
     for (uint32_t s = tid; s < kHashSlots; s += kHashThreads) {
         tab[s] = EMPTY;
         if (OP != 0) pay[s] = 0;
     }
     __syncthreads();
+    BBK_PH(4, 0, t_prev);  // table init
     uint64_t kk[kHashItems];
     uint32_t vv[kHashItems];
 #pragma unroll
@@ -1339,6 +1418,7 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
         }
     }
     __syncthreads();
+    BBK_PH(4, 1, t_prev);  // loads + insert
     // compaction of the occupied slots: thread t owns slots t, t + 512, ... (consecutive lanes read
     // consecutive 8-byte slots: no LDS bank conflicts; the output order is free, the set is unsorted)
     constexpr int SPT = kHashSlots / kHashThreads;
@@ -1378,6 +1458,10 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
             ++o;
         }
     }
+    BBK_PH(4, 2, t_prev);  // compaction + output
+#ifdef BBK_PHASE_PROF
+    if (threadIdx.x == 0) atomicAdd(&g_phase[4][7], 1ull);
+#endif
     if (tid == 0) A.dcount[b] = total;
 }
 
@@ -2261,13 +2345,13 @@ struct MsdRunner {
 
 #ifdef BBK_PHASE_PROF
 static void dump_phases() {
-    unsigned long long h[4][8];
+    unsigned long long h[6][8];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) != hipSuccess) return;
-    static const char *kinds[4] = {"scatter1_reads", "scatter1_keys", "scatter2", "-"};
-    for (int q = 0; q < 3; ++q) {
+    static const char *kinds[6] = {"scatter1_reads", "scatter1_keys", "scatter2", "bucket_dist", "bucket_hash", "-"};
+    for (int q = 0; q < 5; ++q) {
         if (!h[q][7]) continue;
         fprintf(stderr, "[bbk phase] %-15s wgs=%llu cycles/wg:", kinds[q], h[q][7]);
-        for (int p = 0; p < 5; ++p) fprintf(stderr, " p%d=%.0f", p, (double)h[q][p] / (double)h[q][7]);
+        for (int p = 0; p < 7; ++p) fprintf(stderr, " p%d=%.0f", p, (double)h[q][p] / (double)h[q][7]);
         fprintf(stderr, "\n");
     }
     memset(h, 0, sizeof(h));
