@@ -135,12 +135,10 @@ def main():
             ptr, order = s.device_keys()
             assert order == B.ORDER_REFERENCE_BUCKETS16 and (ptr or len(s) == 0)
             return len(s), s
-        both = D.sharded_count(ctx, reads, k, both_strands=True)
-        n2 = len(both)
-        out = torch.empty((n2, nw), dtype=torch.int64, device=dev)
-        both.export_to(out, B.ORDER_REFERENCE_BUCKETS16)
-        both.free()
-        return n2, out
+        both = D.sharded_count(ctx, reads, k, both_strands=True, reference_order=True)
+        ptr, order = both.device_keys()
+        assert order == B.ORDER_REFERENCE_BUCKETS16
+        return len(both), both
 
     def fence():
         if world > 1:

@@ -116,6 +116,8 @@ int bbk_kmerset_from_device_ex(bbk_ctx *ctx, const void *d_keys, const void *d_c
 /* canon U rc(canon): the both-strand set of spades-kmercount from a BBK_CANONICAL set (each rank
  * applies it to its own shard after the multi-GPU exchange). */
 int bbk_kmerset_both_strands(bbk_ctx *ctx, const bbk_kmerset *canon, bbk_kmerset **out);
+/* same; flags = BBK_REFERENCE_ORDER stores the result in the final_kmers order */
+int bbk_kmerset_both_strands_ex(bbk_ctx *ctx, const bbk_kmerset *canon, unsigned flags, bbk_kmerset **out);
 unsigned bbk_words(unsigned k); /* RtSeq::GetDataSize (common/sequence/rtseq.hpp:129-131) */
 uint64_t bbk_kmerset_size(const bbk_kmerset *s);
 unsigned bbk_kmerset_k(const bbk_kmerset *s);

@@ -444,16 +444,37 @@ int bbk_kmerset_from_device_ex(bbk_ctx *ctx, const void *d_keys, const void *d_c
 }
 
 int bbk_kmerset_both_strands(bbk_ctx *ctx, const bbk_kmerset *canon, bbk_kmerset **out) {
+    return bbk_kmerset_both_strands_ex(ctx, canon, 0, out);
+}
+
+int bbk_kmerset_both_strands_ex(bbk_ctx *ctx, const bbk_kmerset *canon, unsigned flags, bbk_kmerset **out) {
     return guarded([&] {
         BBK_REQUIRE(ctx && canon && out, BBK_ERR_ARG, "bbk_kmerset_both_strands: NULL argument");
+        BBK_REQUIRE((flags & ~BBK_REFERENCE_ORDER) == 0, BBK_ERR_ARG,
+                    "bbk_kmerset_both_strands_ex: only BBK_REFERENCE_ORDER is accepted");
         BBK_HIP(hipSetDevice(ctx->device));
+        const bool want_ref = (flags & BBK_REFERENCE_ORDER) != 0;
         auto s = std::make_unique<bbk_kmerset>();
         s->k = canon->k;
         s->W = canon->W;
-        s->flags = (canon->flags & ~BBK_CANONICAL) | BBK_BOTH_STRANDS;
+        s->flags = (canon->flags & ~(BBK_CANONICAL | BBK_UNSORTED)) | BBK_BOTH_STRANDS | flags;
         s->has_counts = canon->has_counts;
         s->instances = 2 * canon->instances;
-        expand_both_strands(ctx, canon->k, canon->keys, canon->has_counts ? &canon->counts : nullptr, canon->n, *s);
+        expand_both_strands(ctx, canon->k, canon->keys, canon->has_counts ? &canon->counts : nullptr, canon->n, *s,
+                            want_ref);
+        if (want_ref && !s->ref_order) {  // key widths without room for the tag: one stable pass on the bucket digit
+            if (s->n) {
+                const PassDesc pd{1, 0, 0, 8, 16};
+                const bool wc = s->has_counts;
+                DevBuf nk(s->n * (size_t)s->W * 8), nc;
+                if (wc) nc.alloc(s->n * 4);
+                partition_records(ctx, (int)s->W, s->keys.p, nk.p, wc ? s->counts.as<uint32_t>() : nullptr,
+                                  wc ? nc.as<uint32_t>() : nullptr, s->n, pd);
+                s->keys = std::move(nk);
+                if (wc) s->counts = std::move(nc);
+            }
+            s->ref_order = true;
+        }
         *out = s.release();
     });
 }

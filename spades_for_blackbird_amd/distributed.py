@@ -58,7 +58,7 @@ def exchange_by_owner(send, send_counts, words, group=None):
     return recv, rcl
 
 
-def sharded_count(ctx, reads, k, both_strands=True, group=None):
+def sharded_count(ctx, reads, k, both_strands=True, group=None, reference_order=False):
     """Count on every rank, exchange distinct canonical k-mers by owner, merge-unique the shard and
     (optionally) expand it to both strands.  Returns the rank's KMerSet shard."""
     import torch
@@ -78,6 +78,7 @@ def sharded_count(ctx, reads, k, both_strands=True, group=None):
     shard = ctx.kmerset_from_device(recv, sum(rcl), k, flags=E.UNSORTED if both_strands else 0)
     if not both_strands:
         return shard
-    both = shard.both_strands()
+    # reference_order: the shard is built in the final_kmers order (16 XXH3 buckets, ascending inside)
+    both = shard.both_strands(E.REFERENCE_ORDER if reference_order else 0)
     shard.free()
     return both

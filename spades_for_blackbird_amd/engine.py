@@ -17,7 +17,7 @@ SYMBOLS = [
     "bbk_reads_from_ascii", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_from_spades_binary",
     "bbk_reads_write_spades_binary", "bbk_reads_count", "bbk_reads_bases",
     "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
-    "bbk_count", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k", "bbk_kmerset_keys",
+    "bbk_count", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_kmerset_both_strands_ex", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k", "bbk_kmerset_keys",
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_free",
@@ -72,6 +72,7 @@ def load_library():
     L.bbk_kmerset_from_device.argtypes = [vp, vp, vp, u64, C.c_uint, C.POINTER(vp)]
     L.bbk_kmerset_from_device_ex.argtypes = [vp, vp, vp, u64, C.c_uint, C.c_uint, C.POINTER(vp)]
     L.bbk_kmerset_both_strands.argtypes = [vp, vp, C.POINTER(vp)]
+    L.bbk_kmerset_both_strands_ex.argtypes = [vp, vp, C.c_uint, C.POINTER(vp)]
     L.bbk_words.restype = C.c_uint
     L.bbk_words.argtypes = [C.c_uint]
     L.bbk_kmerset_size.restype = u64
@@ -302,9 +303,10 @@ class KMerSet(_Handle):
         p = self._L.bbk_kmerset_keys(self._h, C.byref(o))
         return p, int(o.value)
 
-    def both_strands(self):
+    def both_strands(self, flags=0):
+        """canon U rc(canon); flags=REFERENCE_ORDER stores it in the final_kmers order."""
         h = C.c_void_p()
-        _check(self._L.bbk_kmerset_both_strands(self.ctx._h, self._h, C.byref(h)))
+        _check(self._L.bbk_kmerset_both_strands_ex(self.ctx._h, self._h, flags, C.byref(h)))
         return KMerSet(self.ctx, h)
 
     def export(self, order=ORDER_SORTED, with_counts=False):

@@ -30,8 +30,14 @@ def _worker(rank, world, port, q):
         torch.cuda.set_device(0)
         ctx = B.Context(0, stream=torch.cuda.current_stream())
         reads = ctx.reads_synth(20000, read_len=150, genome_len=120000, seed_genome=42, seed_reads=43 + rank)
-        shard = D.sharded_count(ctx, reads, 21, both_strands=True)
-        q.put((rank, shard.export(B.ORDER_SORTED), reads.to_list()))
+        # built in the final_kmers order (what bench.py --gpus N does); the ascending export sorts a copy
+        shard = D.sharded_count(ctx, reads, 21, both_strands=True, reference_order=True)
+        ptr, order = shard.device_keys()
+        asc, ref = shard.export(B.ORDER_SORTED), shard.export(B.ORDER_REFERENCE_BUCKETS16)
+        from oracle import oracle as O
+        bk = np.array([O.bucket(asc[i], 16) for i in range(len(asc))])
+        ref_ok = order == B.ORDER_REFERENCE_BUCKETS16 and np.array_equal(ref, asc[np.argsort(bk, kind="stable")])
+        q.put((rank, asc, reads.to_list(), bool(ref_ok)))
         ctx.close()
     finally:
         dist.destroy_process_group()
@@ -46,7 +52,8 @@ def test_two_ranks_one_gpu():
     procs = [c.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict((r, (k, rd)) for r, k, rd in (q.get(timeout=300) for _ in range(world)))
+    res = dict((r, (k, rd, ok)) for r, k, rd, ok in (q.get(timeout=300) for _ in range(world)))
+    assert all(v[2] for v in res.values()), "a shard is not in the final_kmers order"
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
