@@ -1654,17 +1654,21 @@ __global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, uint64_t n, 
 // ODD on purpose: in the blocked phases thread t reads records t*ITEMS + i, i.e. lanes are ITEMS*W*2
 // dwords apart; with an even ITEMS that stride is a multiple of 16 dwords and a wave hits 2-4 LDS banks
 // (16- to 32-way conflicts); with an odd ITEMS the ds_read_b64/b128 of a lane group are conflict-free.
-// 8-byte keys: 256 threads x 23 records (CAP 5888; two workgroups per CU), second chance 512 x 23.
-// Wider keys: the staged bucket takes most of the LDS (one workgroup per CU), so the same ~5.6 k records
-// are spread over 512 threads x 11 to keep 8 waves on the CU.
+// First pass (k_bucket_dist): 512 threads x 11 records of 8 bytes (CAP 5632), x 7 of 16 bytes (CAP 3584) -- two
+// workgroups per CU and few records per lane (the kernel is issue-bound: 256 x 23 was 20 % slower, 512 x 11
+// records of 16 bytes, one workgroup per CU, 75 % slower).  Second chance (k_bucket, radix): 512 x 23 / 512 x 11.
 template <int W>
 struct BktCfg {
 #ifndef BBK_BKT_NT
-#define BBK_BKT_NT 256
-#define BBK_BKT_ITEMS 23
+#define BBK_BKT_NT 512
+#define BBK_BKT_ITEMS 11
 #endif
-    static constexpr int NT = (W == 1) ? BBK_BKT_NT : 512;
-    static constexpr int ITEMS = (W == 1) ? BBK_BKT_ITEMS : 11;
+#ifndef BBK_BKT2_NT
+#define BBK_BKT2_NT 512
+#define BBK_BKT2_ITEMS 7
+#endif
+    static constexpr int NT = (W == 1) ? BBK_BKT_NT : BBK_BKT2_NT;
+    static constexpr int ITEMS = (W == 1) ? BBK_BKT_ITEMS : BBK_BKT2_ITEMS;
     static constexpr uint32_t CAP = NT * ITEMS;
     static constexpr int NT2 = 512;                               // second-chance kernel
     static constexpr int ITEMS2 = (W == 1) ? 23 : 11;
@@ -1760,7 +1764,11 @@ struct MsdRunner {
     bool use_hash_dedup() const { return W == 1 && dmode == MSD_HASH && 2 * k < 64; }
     bool use_hashidx_dedup() const { return W >= 2 && dmode == MSD_HASH; }
     // records a first-pass bucket kernel can hold
-    uint32_t bucket_cap() const { return use_hashidx_dedup() ? kHashIdxCap : BktCfg<W>::CAP; }
+    uint32_t bucket_cap() const {
+        if (use_hashidx_dedup()) return kHashIdxCap;
+        if (use_hash_dedup()) return (uint32_t)(kHashThreads * kHashItems);
+        return BktCfg<W>::CAP;
+    }
 
     template <int OP>
     void launch_bucket_hashidx(uint32_t nblocks, Key<W> *buf, uint32_t *vals, BucketArgs A, double bytes) {

@@ -195,8 +195,9 @@ def test_unsorted_sets(ctx):
         rk, rc_ = ref.export(B.ORDER_SORTED, with_counts=True)
         u = ctx.count(r, k, B.CANONICAL | B.UNSORTED | B.WITH_COUNTS)
         assert len(u) == len(ref)
-        with pytest.raises(B.BBKError):
-            u.export(B.ORDER_SORTED)
+        if not os.environ.get("BBK_DISABLE_MSD"):  # the general (LSD) path always yields a sorted set
+            with pytest.raises(B.BBKError):
+                u.export(B.ORDER_SORTED)
         part, counts = u.export_by_owner(4)
         order = np.lexsort([part[:, j] for j in range(part.shape[1] - 1, -1, -1)])
         assert np.array_equal(part[order], rk)
