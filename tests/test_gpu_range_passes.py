@@ -6,7 +6,8 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(bool(os.environ.get("BBK_DISABLE_MSD")), reason="tests of the MSD path's modes")]
 
 SCRIPT = r"""
 import numpy as np, sys
