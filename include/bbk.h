@@ -143,6 +143,14 @@ unsigned bbk_extindex_k(const bbk_extindex *x);
 /* sorted canonical k-mers (size*words u64) and their InOutMask bytes
  * (kmer_extension_index.hpp:42-196: bits 0-3 outgoing A,C,G,T; bits 4-7 incoming) */
 int bbk_extindex_export(bbk_ctx *ctx, const bbk_extindex *x, void *dst_keys, void *dst_masks);
+/* Early tip clipping on the index, in place: EarlyTipClipperProcessor(index, length_bound).ClipTips()
+ * (common/assembly_graph/construction/early_simplification.hpp:37-160; the main pipeline calls it between the
+ * extension index and the unitig extraction, stages/construction.cpp:218-275, with length_bound = read length - k
+ * unless configured).  Tips (dead-end branches of at most length_bound k-mers) shorter than the longest outgoing
+ * branch of their junction are isolated (mask 0) and the junction's links to them removed.
+ * *removed_kmers = isolated k-mers (the count the reference logs), *removed_links = links dropped afterwards. */
+int bbk_extindex_clip_tips(bbk_ctx *ctx, bbk_extindex *x, uint32_t length_bound, uint64_t *removed_kmers,
+                           uint64_t *removed_links);
 void bbk_extindex_free(bbk_extindex *x);
 
 /* ---- unitigs + graph links: replaces UnbranchingPathExtractor::ExtractUnbranchingPathsAndLoops

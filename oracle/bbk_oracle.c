@@ -739,6 +739,102 @@ void orc_unitigs_free(orc_unitigs *u) {
     memset(u, 0, sizeof(*u));
 }
 
+/* ---- early tip clipping on the extension index (assembly_graph/construction/early_simplification.hpp) ---- */
+
+/* RemoveInconsistentForwardLinks (:20-35) */
+static size_t remove_inconsistent_forward_links(orc_extindex *x, const kwh_t *kh) {
+    size_t count = 0;
+    uint8_t mask = kwh_mask(x, kh);
+    for (int c = 0; c < 4; ++c) {
+        if (!(mask & (1u << c))) continue;
+        kwh_t next;
+        if (kwh_shl(x, kh, c, &next)) continue;
+        int first = orc_kmer_get(&kh->key, 0);
+        if (!(kwh_mask(x, &next) & (1u << (4 + first)))) {
+            /* DeleteOutgoing(kh, c): bit c of the oriented mask = bit (as_is ? c : 7 - c) of the stored byte
+             * (kmer_extension_index.hpp:67-69,108-114) */
+            x->masks[kh->idx] &= (uint8_t) ~(1u << (kh->minimal ? c : 7 - c));
+            ++count;
+        }
+    }
+    return count;
+}
+
+/* FindForward (:107-118): fills tip[] with the indices of the canonical forms; returns its size (0 = not a tip) */
+static size_t find_forward(const orc_extindex *x, kwh_t kh, size_t length_bound, size_t *tip) {
+    size_t n = 0;
+    for (;;) {
+        uint8_t m = kwh_mask(x, &kh);
+        if (!(n < length_bound && mask_unique_in(m) && mask_unique_out(m))) break;
+        tip[n++] = kh.idx;
+        kwh_t nx;
+        if (kwh_shl(x, &kh, kUniqueNext[m & 0xF], &nx)) return 0;
+        kh = nx;
+    }
+    tip[n++] = kh.idx;
+    uint8_t m = kwh_mask(x, &kh);
+    if (!mask_unique_in(m) || (m & 0xF) != 0) return 0; /* branching or too long */
+    return n;
+}
+
+/* EarlyTipClipperProcessor::ClipTips (:52-96) run by one thread over the k-mer file in order: every stored k-mer and
+ * its reverse complement; a start with >= 2 outgoing edges loses every outgoing tip that is shorter than its longest
+ * outgoing branch (non-tips count as infinitely long), then the phantom links of the tipped junctions are removed.
+ * Returns the number of isolated k-mers; *clipped_links = links removed in the second phase. */
+size_t orc_extindex_clip_tips(orc_extindex *x, size_t length_bound, size_t *clipped_links) {
+    int k = x->k, nw = orc_words(k);
+    size_t removed = 0, n_tipped = 0, cap_tipped = 1024;
+    kwh_t *tipped = (kwh_t *)malloc(cap_tipped * sizeof(kwh_t));
+    size_t *tips[4];
+    for (int c = 0; c < 4; ++c) tips[c] = (size_t *)malloc((length_bound + 2) * sizeof(size_t));
+    for (size_t i = 0; i < x->n_k; ++i) {
+        for (int o = 0; o < 2; ++o) {
+            kwh_t kh;
+            memset(&kh, 0, sizeof(kh));
+            memcpy(kh.key.w, x->kmers + i * nw, (size_t)nw * sizeof(uint64_t));
+            if (o) {
+                orc_kmer r;
+                orc_kmer_rc(&kh.key, k, &r);
+                kh.key = r;
+            }
+            if (kwh_make(x, &kh.key, &kh)) continue;
+            uint8_t mask = kwh_mask(x, &kh);
+            if (__builtin_popcount(mask & 0xF) < 2) continue;
+            /* RemoveForward (:136-149) */
+            size_t len[4] = {0, 0, 0, 0}, max = 0;
+            for (int c = 0; c < 4; ++c) {
+                if (!(mask & (1u << c))) continue;
+                kwh_t khc;
+                if (kwh_shl(x, &kh, c, &khc)) continue;
+                len[c] = find_forward(x, khc, length_bound, tips[c]);
+                size_t l = len[c] ? len[c] : (size_t)-1;
+                if (l > max) max = l;
+            }
+            size_t rm = 0;
+            for (int c = 0; c < 4; ++c) {
+                if (len[c] && len[c] < max) {
+                    for (size_t j = 0; j < len[c]; ++j) x->masks[tips[c][j]] = 0; /* IsolateVertex */
+                    rm += len[c];
+                }
+            }
+            removed += rm;
+            if (rm) {
+                if (n_tipped == cap_tipped) {
+                    cap_tipped *= 2;
+                    tipped = (kwh_t *)realloc(tipped, cap_tipped * sizeof(kwh_t));
+                }
+                tipped[n_tipped++] = kh;
+            }
+        }
+    }
+    size_t links = 0;
+    for (size_t i = 0; i < n_tipped; ++i) links += remove_inconsistent_forward_links(x, &tipped[i]);
+    if (clipped_links) *clipped_links = links;
+    for (int c = 0; c < 4; ++c) free(tips[c]);
+    free(tipped);
+    return removed;
+}
+
 int orc_unitigs_extract(orc_extindex *x, orc_unitigs *out) {
     memset(out, 0, sizeof(*out));
     int k = x->k, nw = orc_words(k);

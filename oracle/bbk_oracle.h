@@ -100,6 +100,11 @@ void orc_extindex_free(orc_extindex *x);
 /* index of a canonical k-mer in merged-file order, or (size_t)-1 */
 size_t orc_extindex_find(const orc_extindex *x, const orc_kmer *canon);
 
+/* ---- early tip clipping (assembly_graph/construction/early_simplification.hpp:37-160) ---- */
+/* EarlyTipClipperProcessor(index, length_bound).ClipTips(): modifies the masks in place; returns the number of
+ * isolated k-mers ("<n> (k+1)-mers were removed by early tip clipper"), *clipped_links the phantom links removed */
+size_t orc_extindex_clip_tips(orc_extindex *x, size_t length_bound, size_t *clipped_links);
+
 /* ---- unitigs (assembly_graph/construction/debruijn_graph_constructor.hpp:182-388) ---- */
 typedef struct {
     size_t n;          /* paths + loops, reference order (loops last) */

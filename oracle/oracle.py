@@ -200,6 +200,17 @@ class ExtIndex:
             if s.n_k else np.zeros((0, nw), np.uint64)
         self.masks = np.ctypeslib.as_array(s.masks, shape=(s.n_k,)).copy() if s.n_k else np.zeros(0, np.uint8)
 
+    def clip_tips(self, length_bound):
+        """EarlyTipClipperProcessor::ClipTips on the masks held in C; returns (isolated k-mers, removed links) and
+        refreshes self.masks."""
+        links = C.c_size_t(0)
+        lib().orc_extindex_clip_tips.restype = C.c_size_t
+        lib().orc_extindex_clip_tips.argtypes = [C.POINTER(_ExtIndex), C.c_size_t, C.POINTER(C.c_size_t)]
+        removed = lib().orc_extindex_clip_tips(C.byref(self._st), length_bound, C.byref(links))
+        s = self._st
+        self.masks = np.ctypeslib.as_array(s.masks, shape=(s.n_k,)).copy() if s.n_k else np.zeros(0, np.uint8)
+        return int(removed), int(links.value)
+
     def unitigs(self):
         """Runs UnbranchingPathExtractor (destroys the masks held in C, like the reference)."""
         return Unitigs(self)

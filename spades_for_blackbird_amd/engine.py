@@ -20,7 +20,7 @@ SYMBOLS = [
     "bbk_count", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_kmerset_both_strands_ex", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k", "bbk_kmerset_keys",
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
-    "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_free",
+    "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_clip_tips", "bbk_extindex_free",
     "bbk_unitigs_build", "bbk_unitigs_add_coverage", "bbk_unitigs_export_kc", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
     "bbk_unitigs_vertices", "bbk_unitigs_links", "bbk_unitigs_export", "bbk_unitigs_export_links",
     "bbk_unitigs_write_gfa", "bbk_unitigs_write_fasta", "bbk_unitigs_write_fastg", "bbk_unitigs_free",
@@ -94,6 +94,7 @@ def load_library():
         L.bbk_extindex_k.restype = C.c_uint
         L.bbk_extindex_k.argtypes = [vp]
         L.bbk_extindex_export.argtypes = [vp, vp, vp, vp]
+        L.bbk_extindex_clip_tips.argtypes = [vp, vp, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
         L.bbk_extindex_free.argtypes = [vp]
     if hasattr(L, "bbk_unitigs_build"):
         L.bbk_unitigs_build.argtypes = [vp, vp, C.POINTER(vp)]
@@ -343,6 +344,12 @@ class ExtIndex(_Handle):
     @property
     def k(self):
         return int(self._L.bbk_extindex_k(self._h))
+
+    def clip_tips(self, length_bound):
+        """EarlyTipClipperProcessor(index, length_bound).ClipTips() in place; returns (isolated k-mers, removed links)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(self._L.bbk_extindex_clip_tips(self.ctx._h, self._h, length_bound, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def export(self):
         n, nw = len(self), words(self.k)

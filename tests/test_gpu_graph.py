@@ -274,3 +274,33 @@ def test_long_reads_and_long_unitigs(ctx, tmp_path):
     r = ctx.reads_from_ascii(reads)
     got = ctx.count(r, k, B.BOTH_STRANDS).export(B.ORDER_REFERENCE_BUCKETS16)
     assert np.array_equal(got, O.kmercount(reads, k, 16, 2))
+
+
+@pytest.mark.parametrize("k,bound", [(21, 129), (21, 10), (33, 117), (55, 95), (77, 20)])
+def test_early_tip_clipping(ctx, k, bound):
+    """bbk_extindex_clip_tips vs the oracle's restatement of EarlyTipClipperProcessor::ClipTips
+    (early_simplification.hpp:37-160): same isolated k-mers, same removed links, identical masks afterwards, and the
+    unitigs of the clipped index agree in canonical form.  Sequencing errors near read ends give thousands of tips.
+    No reference fixture exists for this step ("parity unpinned": the oracle is the restated algorithm)."""
+    reads = synth_reads(2500, read_len=150, genome_len=20000, sub_rate=0.01, seed=31 + k, n_rate=0.001)
+    reads += ["ACGT" * 40, "A" * 150]
+    ox = O.ExtIndex(reads, k, 1)
+    exp_removed, exp_links = ox.clip_tips(bound)
+    assert exp_removed > 0
+    x = ctx.extindex(ctx.reads_from_ascii(reads), k)
+    removed, links = x.clip_tips(bound)
+    assert (removed, links) == (exp_removed, exp_links)
+    order = np.lexsort([ox.kmers[:, j] for j in range(ox.kmers.shape[1] - 1, -1, -1)])
+    gk, gm = x.export()
+    assert np.array_equal(gk, ox.kmers[order])
+    assert np.array_equal(gm, ox.masks[order])
+    # the clipped index still compacts: same unitig multiset as the oracle (orientation-free)
+    u = ctx.unitigs(x)
+    ou = ox.unitigs()
+    got = sorted(min(s, rc(s)) for s in u.sequences())
+    exp = sorted(min(s, rc(s)) for s in ou.seqs)
+    assert got == exp
+    # idempotent on an index without short tips left: a second pass with the same bound removes nothing new only
+    # if no new tips arose; the reference makes no such promise, so just check it runs and stays consistent
+    removed2, links2 = x.clip_tips(bound)
+    assert removed2 >= 0 and links2 >= 0

@@ -227,3 +227,35 @@ def test_unitig_invariants_random():
         cover = oriented_edge_cover(u.seqs, k)
         assert len(cover) == len(set(cover))
         assert set(cover) == E
+
+
+def test_oracle_early_tip_clipper_semantics():
+    """orc_extindex_clip_tips (restated EarlyTipClipperProcessor, early_simplification.hpp:37-160) on a case worked
+    by hand: one read with a substitution 5 bases before its end adds a dead-end branch of 5 k-mers next to the true
+    path; clipping isolates exactly those and restores the masks of the error-free index.  (The reference ships no
+    fixture for this step; this pins the restatement to the algorithm's definition.)"""
+    import random
+    rnd = random.Random(7)
+    k, L = 21, 100
+    genome = "".join(rnd.choice("ACGT") for _ in range(400))
+    clean = [genome[i:i + L] for i in range(0, len(genome) - L + 1, 10)]
+    bad = list(genome[100:100 + L])
+    pos = L - 5
+    bad[pos] = {"A": "C", "C": "G", "G": "T", "T": "A"}[bad[pos]]
+    ox_clean = O.ExtIndex(clean, k, 1)
+    ox = O.ExtIndex(clean + ["".join(bad)], k, 1)
+    assert ox.n_k == ox_clean.n_k + 5
+    removed, links = ox.clip_tips(L - k)
+    assert (removed, links) == (5, 1)
+    ref = {tuple(r): m for r, m in zip(ox_clean.kmers.tolist(), ox_clean.masks.tolist())}
+    extra = 0
+    for r, m in zip(ox.kmers.tolist(), ox.masks.tolist()):
+        if tuple(r) in ref:
+            assert m == ref[tuple(r)]
+        else:
+            assert m == 0
+            extra += 1
+    assert extra == 5
+    # a bound shorter than the tip leaves it alone
+    ox2 = O.ExtIndex(clean + ["".join(bad)], k, 1)
+    assert ox2.clip_tips(3) == (0, 0)
