@@ -1,4 +1,4 @@
-"""Builds the C++ host programs (the two CLI drop-ins) against libbbk.so with g++ (in-tree)."""
+"""Builds the C++ host programs (the CLI drop-ins) against libbbk.so with g++ (in-tree)."""
 import os
 import subprocess
 import sys
@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HOST = os.path.join(HERE, "host")
 BIN = os.path.join(HERE, "bin")
 PROGRAMS = {"spades-kmercount": "kmercount_main.cpp", "spades-gbuilder": "gbuilder_main.cpp",
-            "bbk-fastx-dump": "fastx_dump_main.cpp"}
+            "spades-kmer-estimating": "kmer_estimating_main.cpp", "bbk-fastx-dump": "fastx_dump_main.cpp"}
 HEADERS = ["common.hpp", "dataset.hpp", "fastx.hpp"]
 
 

@@ -60,3 +60,33 @@ def test_gbuilder_cli_toy(bins, golden, golden_dir, tmp_path):
     fa = open(out2).read()
     assert fa.startswith(">EDGE_1_length_")
     assert fa.count(">") == g["k21"]["n_unitigs"]
+
+
+def test_kmer_estimating_cli_toy(bins, golden, golden_dir, tmp_path):
+    """spades-kmer-estimating drop-in: the reference prints a HyperLogLog ESTIMATE of the number of distinct k-mers
+    (strands identified); the engine prints the exact number, checked here against the oracle's canonical set (the
+    both-strand set of the toy data minus its self-reverse-complementary k-mers, halved)."""
+    import numpy as np
+    g = golden["toy_kmercount"]
+    files = [os.path.join(golden_dir, f) for f in g["files"]]
+    y = tmp_path / "toy.yaml"
+    y.write_text("- left reads: [%s]\n  orientation: fr\n  right reads: [%s]\n  type: paired-end\n" % tuple(files))
+    reads = []
+    for f in files:
+        reads += read_fastq_gz(f)
+    for k in (21, 22, 55):
+        both = O.kmercount(reads, k, 16, 2)
+        canon = set()  # one representative per {k-mer, reverse complement} class
+        for row in both.tolist():
+            s = "".join("ACGT"[(row[i // 32] >> (2 * (i % 32))) & 3] for i in range(k))  # RtSeq layout
+            canon.add(min(s, rcs(s)))
+        r = subprocess.run([bins["spades-kmer-estimating"], "-k", str(k), "-d", str(y), "-t", "4"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "Kmer number estimation: %d" % len(canon) in r.stdout
+    r = subprocess.run([bins["spades-kmer-estimating"], "-k", "21"], capture_output=True, text=True)
+    assert r.returncode == 1 and "SYNOPSIS" in r.stdout  # -d is required
+
+
+def rcs(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
