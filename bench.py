@@ -111,8 +111,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # BBK_BENCH_FORCE_SHARDED=1: take the N>1 code path (owner partition, RCCL all_to_all, merge, expand) with a
+    # single rank -- the only way to exercise it on a one-GPU box
+    sharded = world > 1 or os.environ.get("BBK_BENCH_FORCE_SHARDED") == "1"
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
@@ -129,7 +133,7 @@ def main():
 
     def step():
         """Returns (#records of this rank's part of the result, keep-alive)."""
-        if world == 1:
+        if not sharded:
             # the set is built in the final_kmers order (what spades-kmercount leaves on disk) and stays in HBM
             s = ctx.count(reads, k, B.BOTH_STRANDS | B.REFERENCE_ORDER)
             ptr, order = s.device_keys()
@@ -141,7 +145,7 @@ def main():
         return len(both), both
 
     def fence():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -167,7 +171,7 @@ def main():
 
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     nn = torch.tensor([n_rec], dtype=torch.int64, device=dev)
-    if world > 1:
+    if sharded:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)
     dt_max = float(tt.item())
@@ -215,7 +219,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ctx, args, B)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -48,14 +48,38 @@ def exchange_by_owner(send, send_counts, words, group=None):
         # gloo has no device all_to_all: stage through the host (tests of the sharded path on one GPU)
         recv, rcl = exchange_by_owner(send.cpu(), send_counts, words, group)
         return recv.to(dev), rcl
+    rank = dist.get_rank(group)
     sc = torch.tensor([int(x) for x in send_counts], dtype=torch.int64, device=dev)
     rc = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(rc, sc, group=group)
     rcl = [int(x) for x in rc.tolist()]
-    recv = torch.empty((sum(rcl), words), dtype=torch.int64, device=dev)
-    dist.all_to_all_single(recv.view(-1), send.contiguous().view(-1), [x * words for x in rcl],
-                           [int(x) * words for x in send_counts], group=group)
-    return recv, rcl
+    send = send.contiguous()
+    # The rank's own segment never enters the collective: it is copied on the device, and the collective carries
+    # the 7 peer segments only (one message per xGMI link).  The received records are a set, so the own segment
+    # simply goes last.  (A one-rank RCCL all_to_all of the whole buffer returned before the data had arrived.)
+    own = int(send_counts[rank])
+    before = sum(int(x) for x in send_counts[:rank])
+    n_peers = sum(rcl) - rcl[rank]
+    recv = torch.empty((n_peers + own, words), dtype=torch.int64, device=dev)
+    out_split = [x * words for x in rcl]
+    in_split = [int(x) * words for x in send_counts]
+    out_split[rank] = 0
+    in_split[rank] = 0
+    # input = the send buffer without the own segment (views, no copy, when the own segment is first or last)
+    if own == 0:
+        src = send.view(-1)
+    elif before == 0:
+        src = send[own:].view(-1)
+    elif before + own == send.shape[0]:
+        src = send[:before].view(-1)
+    else:
+        src = torch.cat((send[:before], send[before + own:])).view(-1)
+    if world > 1:
+        dist.all_to_all_single(recv[:n_peers].view(-1), src, out_split, in_split, group=group)
+    if own:
+        recv[n_peers:].copy_(send[before:before + own])
+    rcl_out = list(rcl)
+    return recv, rcl_out
 
 
 def sharded_count(ctx, reads, k, both_strands=True, group=None, reference_order=False):
