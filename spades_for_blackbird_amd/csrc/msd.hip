@@ -1687,6 +1687,7 @@ struct MsdRunner {
     bool in_vals;  // records carry a payload from the start (mask extraction or input counts)
     uint64_t strip_mask = ~0ull;  // tagged sort: bits of word 0 that survive in the output
     bool slots_ok = getenv("BBK_NO_SLOTS") == nullptr;  // histogram-free slot mode allowed (HASH prefix)
+    bool never_decline = false;  // finish whatever overflows bucket by bucket on the LSD path instead of declining
 
     template <bool HAS_VAL, bool HIST>
     void launch_part(const char *fam, double bytes, uint32_t ntiles, const Key<W> *in, const uint32_t *vin, TileMap M,
@@ -1857,9 +1858,6 @@ struct MsdRunner {
             out.vals.alloc(16);
             return 1;
         }
-        BBK_REQUIRE(N < (1ull << 32) - kPartTileK, BBK_ERR_ARG,
-                    "batch holds %llu records; a single device batch is limited to 2^32-1 (split the input)",
-                    (unsigned long long)N);
         if (sel_bits == 0 && from_reads && dmode == MSD_HASH && N > pass_limit() && need_sel_bits) {
             int bits = 1;
             while ((N >> bits) > pass_limit() && bits < 8) ++bits;
@@ -1868,6 +1866,11 @@ struct MsdRunner {
         }
         const uint64_t Ntot = N;        // instance space of the level-1 tiles
         if (sel_bits) N = (N >> sel_bits) + (N >> (sel_bits + 4)) + 1;  // planning estimate of this range's share
+        // record offsets inside one pass are 32-bit; the reads of a call may hold more (hash-range passes walk
+        // the 64-bit chunk space of the reads once per range)
+        BBK_REQUIRE(N < (1ull << 32) - kPartTileK, BBK_ERR_ARG,
+                    "batch holds %llu records%s; one pass is limited to 2^32-1 (split the input)",
+                    (unsigned long long)N, sel_bits ? " in one of 256 hash ranges" : "");
 
         // ---- bin plan: nb1 (power of two) level-1 bins; level-2 bin counts are chosen per segment below
         const double target = kBucketFill * bucket_cap();
@@ -2180,8 +2183,13 @@ struct MsdRunner {
                 for (uint32_t b : over_seg) put(bufA.p, valA.as<uint32_t>(), (uint64_t)b * seg_cap, seg_cap);
                 for (uint32_t b : over_bkt) put(bufB.p, valB.as<uint32_t>(), (uint64_t)b * stride2, cap2);
                 BBK_HIP(hipStreamSynchronize(ctx->stream));
+                // The records were selected BY their hash bucket, so the same hash would pile them up again:
+                // partition them by key instead (the order of the result does not matter), and never decline --
+                // a k-mer with a million instances is finished by the per-bucket LSD fallback.
                 MsdRunner<W> exact = *this;
                 exact.slots_ok = false;
+                exact.dmode = MSD_KEYS;
+                exact.never_decline = true;
                 // declined (e.g. one k-mer makes up most of it): so does this call, the caller takes the LSD path
                 if (!exact.run_all(nullptr, ek.p, has_val ? ev.as<uint32_t>() : nullptr, n_extra, false, extra)) return 0;
                 extra.bucket_off.release();
@@ -2232,7 +2240,7 @@ struct MsdRunner {
                         dmode, (unsigned long long)N, nb1, nbuckets, mx, bucket_cap(), big.size(), (unsigned long long)novf,
                         (unsigned long long)ovf_rec);
             }
-            if (novf > 256 || ovf_rec > N / 4) return 0;
+            if (!never_decline && (novf > 256 || ovf_rec > N / 4)) return 0;
             if (novf) {
                 const ReduceOp rop = op == MSD_OP_OR ? REDUCE_OR : (op == MSD_OP_SUM ? REDUCE_SUM : REDUCE_COUNT);
                 for (uint32_t b = 0; b < nbuckets; ++b) {
