@@ -302,3 +302,22 @@ def test_reference_order_flag(ctx, golden, golden_dir, k):
         assert hashlib.md5(s.export(B.ORDER_REFERENCE_BUCKETS16).tobytes()).hexdigest() == g["k21"]["md5"]
     with pytest.raises(B.BBKError):
         ctx.count(ctx.reads_from_ascii(reads), k, B.CANONICAL | B.REFERENCE_ORDER | B.UNSORTED)
+
+
+def test_heavy_hitters_at_default_thresholds(ctx):
+    """300 k reads (39 M k-mer instances: the histogram-free slot mode is on by default at this size) of which a
+    fifth are poly-A / tandem repeats: single k-mers with millions of instances overflow their segment slot, the
+    spill list and the exact pass take over; counts must equal the oracle."""
+    reads = synth_reads(240_000, read_len=150, genome_len=600_000, sub_rate=0.005, seed=77)
+    reads += ["A" * 150] * 30_000 + ["ACGT" * 37 + "AC"] * 20_000 + ["AAC" * 50] * 10_000
+    r = ctx.reads_from_ascii(reads)
+    exp, expc = O.kmercount(reads, 21, 16, 8, with_counts=True)
+    s = ctx.count(r, 21, B.BOTH_STRANDS | B.WITH_COUNTS)
+    got, gotc = s.export(B.ORDER_REFERENCE_BUCKETS16, with_counts=True)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(gotc, expc)
+    assert int(gotc.max()) > 3_000_000
+    s2 = ctx.count(r, 21, B.BOTH_STRANDS | B.REFERENCE_ORDER)
+    assert np.array_equal(s2.export(B.ORDER_REFERENCE_BUCKETS16), exp)
+    x = ctx.extindex(r, 21)
+    assert len(x) > 0
