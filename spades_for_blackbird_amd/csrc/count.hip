@@ -267,12 +267,15 @@ static void expand_both_strands(bbk_ctx *ctx, unsigned k, const DevBuf &ck, cons
                                             wc ? ec.as<uint32_t>() : nullptr, tag));
         if (msd_enabled()) {
             MsdOutput m;
-            if (msd_sort_reduce(ctx, k, MSD_KEYS, wc ? MSD_OP_SUM : MSD_OP_NONE, nullptr, e.p,
+            // 16-byte keys have no spare bits in word 0 for the tag: the REF prefix (XXH3 bucket, then key bits)
+            // partitions them into the final_kmers order directly, at the price of the hash in every level
+            const bool ref_prefix = want_ref && !tag && W == 2;
+            if (msd_sort_reduce(ctx, k, ref_prefix ? MSD_REF : MSD_KEYS, wc ? MSD_OP_SUM : MSD_OP_NONE, nullptr, e.p,
                                 wc ? ec.as<uint32_t>() : nullptr, 2 * D, false, m, tag ? 4u : 0u)) {
                 s.n = m.n;
                 s.keys = std::move(m.keys);
                 if (wc) s.counts = std::move(m.vals);
-                s.ref_order = tag;
+                s.ref_order = tag || ref_prefix;
                 return;
             }
         }

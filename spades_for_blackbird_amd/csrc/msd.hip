@@ -1881,6 +1881,10 @@ struct MsdRunner {
             nb1 <<= 1;
             ++b1;
         }
+        if (dmode == MSD_REF && b1 < 4) {  // the 4 bucket bits must be consumed by level 1: a bucket (sorted by key
+            b1 = 4;                        // alone) may not hold records of two XXH3 buckets
+            nb1 = 16;
+        }
         const bool verbose = getenv("BBK_VERBOSE") != nullptr;
         if (want / nb1 > 0.75 * kMaxBins) {  // would need a third level: leave to the LSD path
             if (verbose) fprintf(stderr, "[bbk] msd declines: N=%llu needs more than two levels\n", (unsigned long long)N);

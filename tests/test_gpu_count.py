@@ -127,6 +127,12 @@ def test_larger_batch_properties(ctx):
     # bucket ids ascend along the reference order
     b = [O.bucket(row, 16) for row in ref[:: max(1, len(ref) // 5000)]]
     assert b == sorted(b)
+    # a set built directly in the reference order (tagged sort for 8-byte keys, REF prefix for 16-byte keys) equals
+    # the ascending set reordered by the one stable bucket pass
+    for kk in (21, 55):
+        direct = ctx.count(r, kk, B.BOTH_STRANDS | B.REFERENCE_ORDER).export(B.ORDER_REFERENCE_BUCKETS16)
+        generic = ctx.count(r, kk, B.BOTH_STRANDS).export(B.ORDER_REFERENCE_BUCKETS16)
+        assert np.array_equal(direct, generic), kk
 
 
 def test_owner_partition(ctx):
