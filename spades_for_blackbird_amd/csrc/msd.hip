@@ -571,9 +571,13 @@ __device__ __forceinline__ void chunk_records(const ChunkWords C, uint32_t k_, c
     //   Ft = fwd << pad (base 0 at bit pad, base k-1 at bits 62..63), Rv = rev2(fwd) (base 0 at the top)
     //   step: Ft = (Ft >> 2) & himask | b << 62,  Rv = Rv << 2 | b << pad
     //   canonical test (base-lexicographic fwd <= rc, rtseq.hpp:407-415): Rv <= ~Ft & himask
-    const uint32_t pad = W == 1 ? 64u - 2u * k_ : 0u;
+    // 16-byte keys (k = 33..64): the same with 128-bit state {hi, lo} -- Ft = F << pad (pad = 128 - 2k < 64, only
+    // the low word has padding), Rv = {rev2(w0), rev2(w1)}; ~50 VALU per step against ~135 for a fresh extraction,
+    // reverse complement and base-order comparison.
+    const uint32_t pad = W == 1 ? 64u - 2u * k_ : (W == 2 ? 128u - 2u * k_ : 0u);
     const uint64_t himask = ~0ull << pad;
-    uint64_t Ft = 0, Rv = 0;
+    uint64_t Ft = 0, Rv = 0;      // 8-byte keys; low words of the 128-bit state
+    uint64_t FtH = 0, RvH = 0;    // high words (16-byte keys)
     uint32_t inb = 0;    // bases p+k, p+k+1, ...: the ones that enter (and the outgoing-edge bases)
     uint32_t prevb = 0;  // bases p-1, p, ...: the incoming-edge bases
     if (W == 1 && C.cnt) {
@@ -583,6 +587,18 @@ __device__ __forceinline__ void chunk_records(const ChunkWords C, uint32_t k_, c
         Rv = rev2(Ft >> pad);
         inb = (uint32_t)bases_from(rw, C.p + k_, lastw);
         if (HAS_VAL) prevb = ((uint32_t)f << 2) | (C.p ? base_at(rw, C.p - 1u) : 0u);
+    }
+    if (W == 2 && C.cnt) {
+        const uint32_t lastw = (C.len - 1u) >> 5;
+        const uint64_t w0 = bases_from(rw, C.p, lastw);                                   // bases p .. p+31
+        const uint64_t w1 = (bases_from(rw, C.p + 32u, lastw) << pad) >> pad;              // bases p+32 .. p+k-1
+        // F << pad as {hi, lo}
+        FtH = pad ? (w1 << pad) | (w0 >> (64u - pad)) : w1;
+        Ft = w0 << pad;
+        RvH = rev2(w0);
+        Rv = rev2(w1);
+        inb = (uint32_t)bases_from(rw, C.p + k_, lastw);
+        if (HAS_VAL) prevb = ((uint32_t)w0 << 2) | (C.p ? base_at(rw, C.p - 1u) : 0u);
     }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -602,6 +618,22 @@ __device__ __forceinline__ void chunk_records(const ChunkWords C, uint32_t k_, c
                 }
                 minimal = Rv <= (~Ft & himask);
                 keys[i].w[0] = (minimal ? Ft : ~Rv) >> pad;
+                nextc = (inb >> (2 * i)) & 3u;
+                prevc = (prevb >> (2 * i)) & 3u;
+            } else if constexpr (W == 2) {
+                if (i > 0) {
+                    const uint64_t b = (inb >> (2 * (i - 1))) & 3u;
+                    Ft = ((Ft >> 2) | (FtH << 62)) & himask;
+                    FtH = (FtH >> 2) | (b << 62);
+                    RvH = (RvH << 2) | (Rv >> 62);
+                    Rv = (Rv << 2) | (b << pad);
+                }
+                // canonical test: Rv <= ~Ft & himask128 as 128-bit numbers
+                const uint64_t cH = ~FtH, cL = ~Ft & himask;
+                minimal = RvH < cH || (RvH == cH && Rv <= cL);
+                const uint64_t xH = minimal ? FtH : ~RvH, xL = minimal ? Ft : ~Rv;
+                keys[i].w[0] = pad ? (xL >> pad) | (xH << (64u - pad)) : xL;
+                keys[i].w[1] = xH >> pad;
                 nextc = (inb >> (2 * i)) & 3u;
                 prevc = (prevb >> (2 * i)) & 3u;
             } else {
