@@ -131,6 +131,14 @@ int bbk_kmerset_export(bbk_ctx *ctx, const bbk_kmerset *s, unsigned order, void 
  * records grouped by owner to dst (host or device) and the per-owner record counts to h_counts. */
 int bbk_kmerset_export_by_owner(bbk_ctx *ctx, const bbk_kmerset *s, unsigned nranks, void *dst_keys,
                                 void *dst_counts, uint64_t *h_counts);
+/* The device side of spades-read-filter: io::CoverageFilter / CountMedianMlt
+ * (common/io/reads/coverage_filtering_read_wrapper.hpp:22-76, projects/kmercount/read_filter.cpp:76-121): h_keep[i] = 1
+ * when the upper median of the multiplicities of read i's k-mers (strands identified) is >= threshold (the tool passes
+ * its -c value + 1).  `counts` must be the ascending canonical set with counts of the whole dataset
+ * (bbk_count(BBK_CANONICAL | BBK_WITH_COUNTS)).  Reads shorter than k have median 0.  For a pair the tool keeps both
+ * mates when either passes (coverage_filtering_read_wrapper.hpp:78-94). */
+int bbk_reads_median_filter(bbk_ctx *ctx, const bbk_reads *reads, const bbk_kmerset *counts, unsigned threshold,
+                            uint8_t *h_keep, uint64_t *n_kept);
 void bbk_kmerset_free(bbk_kmerset *s);
 /* Writes <path> in the final_kmers format (raw little-endian records, no header). */
 int bbk_kmerset_write_final_kmers(bbk_ctx *ctx, const bbk_kmerset *s, const char *path);

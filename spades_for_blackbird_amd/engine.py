@@ -17,7 +17,7 @@ SYMBOLS = [
     "bbk_reads_from_ascii", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_from_spades_binary",
     "bbk_reads_write_spades_binary", "bbk_reads_count", "bbk_reads_bases",
     "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
-    "bbk_count", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_kmerset_both_strands_ex", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k", "bbk_kmerset_keys",
+    "bbk_count", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_kmerset_both_strands_ex", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k", "bbk_kmerset_keys", "bbk_reads_median_filter",
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_clip_tips", "bbk_extindex_free",
@@ -213,6 +213,16 @@ class Context:
         h = C.c_void_p()
         _check(self._L.bbk_kmerset_from_device_ex(self._h, _ptr(d_keys), _ptr(d_counts), n, k, flags, C.byref(h)))
         return KMerSet(self, h)
+
+    def median_filter(self, reads, counts, threshold):
+        """CoverageFilter::CheckMedianMlt for every read: uint8[n] (1 = keep), see bbk_reads_median_filter."""
+        keep = np.zeros(len(reads), dtype=np.uint8)
+        kept = C.c_uint64(0)
+        self._L.bbk_reads_median_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p,
+                                                    C.POINTER(C.c_uint64)]
+        _check(self._L.bbk_reads_median_filter(self._h, reads._h, counts._h, threshold, _ptr(keep), C.byref(kept)))
+        assert int(kept.value) == int(keep.sum())
+        return keep
 
     def extindex(self, reads, k):
         """DeBruijnExtensionIndexBuilder::BuildExtensionIndexFromStream analogue."""

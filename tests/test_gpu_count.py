@@ -327,3 +327,33 @@ def test_heavy_hitters_at_default_thresholds(ctx):
     assert np.array_equal(s2.export(B.ORDER_REFERENCE_BUCKETS16), exp)
     x = ctx.extindex(r, 21)
     assert len(x) > 0
+
+
+@pytest.mark.parametrize("k", [21, 33, 77])
+def test_median_multiplicity_read_filter(ctx, k):
+    """bbk_reads_median_filter (the device side of spades-read-filter: CoverageFilter::CheckMedianMlt,
+    coverage_filtering_read_wrapper.hpp:22-76) against a direct evaluation: per read the upper median
+    (nth_element at nk/2) of the canonical k-mer multiplicities of the whole read set, compared with the threshold.
+    Odd k only in the oracle comparison (no self-reverse-complementary k-mers, whose both-strand count doubles)."""
+    deep = synth_reads(1500, read_len=150, genome_len=4000, sub_rate=0.01, seed=5, n_rate=0.002)     # ~55x
+    shallow = synth_reads(300, read_len=150, genome_len=30000, sub_rate=0.01, seed=6, n_rate=0.002)  # ~1.5x
+    reads = deep + shallow + ["", "ACGT", "ACGTTGCA" * 12, "N" * 80, "T" * 150]
+    r = ctx.reads_from_ascii(reads)
+    cset = ctx.count(r, k, B.CANONICAL | B.WITH_COUNTS)
+    both, cnt = O.kmercount(reads, k, 16, 2, with_counts=True)
+    mult = {tuple(row): int(c) for row, c in zip(both.tolist(), cnt.tolist())}
+    for thr in (1, 3, 8):
+        got = ctx.median_filter(r, cset, thr)
+        exp = np.zeros(len(reads), dtype=np.uint8)
+        for i, s in enumerate(reads):
+            a, b = O.longest_valid(s)
+            seg = s[a:b].upper()
+            nk = len(seg) - k + 1
+            if nk <= 0:
+                continue  # median 0 < thr
+            m = sorted(mult[tuple(O.kmer_words(seg[p:p + k]))] for p in range(nk))
+            exp[i] = 1 if m[nk // 2] >= thr else 0
+        assert np.array_equal(got, exp), (k, thr)
+        assert 0 < int(got.sum()) < len(reads)
+    with pytest.raises(B.BBKError):
+        ctx.median_filter(r, ctx.count(r, k, B.BOTH_STRANDS | B.WITH_COUNTS), 2)  # needs the canonical set
