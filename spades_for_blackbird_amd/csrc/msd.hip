@@ -1,28 +1,36 @@
 // msd.hip -- the fast sort-and-count path: two MSD radix-partition levels in HBM, then one
-// workgroup per bucket sorts + reduces its keys entirely in LDS.
+// workgroup per bucket deduplicates / sorts + reduces its keys entirely in LDS.
 //
 // Why: the LSD path (primitives.hip) moves every record 3x per 8-bit pass (k=21: 6 passes, ~19 N*W
 // bytes).  Here a record is written by the (fused) extraction+partition, read and written once
-// more by the second partition level and read once by the bucket kernel: ~5 N*W bytes, independent
-// of the key length, and the duplicate-heavy k-mer stream (50x coverage) collapses inside LDS.
+// more by the second partition level and read once by the bucket kernel, independent of the key
+// length, and the duplicate-heavy k-mer stream (50x coverage) collapses inside LDS.
 //
-//   k_part_hist  : digit histogram of a level (from reads: k-mers are re-extracted, nothing is
-//                  stored; from keys: one coalesced read)                       [LDS ds_add]
-//   k_part       : LDS histogram with returning ds_add = local rank, one global atomicAdd per
+//   k_part_reads : fused k-mer extraction (chunks of one read per lane, rolled) + level-1 partition:
+//                  LDS histogram with returning ds_add = local rank, one global atomicAdd per
 //                  (tile, non-empty bin) reserves the output run, keys reordered in LDS so that a
 //                  wave stores contiguous per-bin runs (unstable: the buckets get sorted later)
-//   k_bucket     : <= CAP keys of one bucket in LDS; LSD radix sort over the key bits with 64-wide
-//                  ballot match-any ranking; head flags + segmented reduce (count / sum / OR);
-//                  distinct records written back in place, count per bucket
+//   k_part       : the same over a key array (levels 1 and 2); <HIST> variants only count
+//   k_bucket_hash / k_bucket_hashidx : one bucket in an LDS open-addressing table: dedup + reduce
+//                  (HASH prefix: the order does not matter)
+//   k_bucket_dist: one bucket sorted in LDS by one distribution pass + in-bin ranking, head flags +
+//                  segmented reduce (count / sum / OR); k_bucket (ballot-ranked LSD radix) is the
+//                  second chance for crowded bins and oversized buckets
 //   k_compact    : buckets -> dense output
 //
-// The partition digit comes from a 64-bit "prefix" p(key): HASH (mix64: uniform whatever the
-// sequence composition; used when only the distinct set matters), KEYS (the key's own top bits:
+// Two modes (MsdRunner::run): the exact mode counts every level first (histogram kernels, dense
+// layout); the slot mode (HASH prefix) gives segments and buckets fixed slots and sends what does
+// not fit to a spill list that the exact mode finishes -- no histogram passes.
+//
+// The partition digit comes from a 32-bit "prefix" p(key): HASH (multiplicative mix: uniform whatever
+// the sequence composition; used when only the distinct set matters), KEYS (the key's own top bits:
 // output globally ascending) or REF (XXH3 bucket of 16, then key bits: the final_kmers order,
 // reference kmer_buckets.hpp:28-33 + kmer_index_builder.hpp:168-181).  Level 2 maps the
 // remaining prefix bits monotonically onto nb2 bins, so bucket order == prefix order.
 // Buckets larger than CAP (a k-mer repeated thousands of times, skewed composition in KEYS mode)
 // are finished by the LSD path, per bucket; if too much overflows the caller falls back entirely.
+// Environment knobs (tests / diagnostics): BBK_DISABLE_MSD, BBK_NO_SLOTS, BBK_SLOTS_MIN, BBK_NO_DIST,
+// BBK_PASS_LIMIT, BBK_VERBOSE; -DBBK_PHASE_PROF builds per-phase shader clocks into the kernels.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
