@@ -56,7 +56,7 @@ namespace bbk {
 #endif
 template <int W>
 struct PartCfg {
-    static constexpr int TILE = (W == 1) ? BBK_KEYS_TILE : 4096;
+    static constexpr int TILE = (W == 1) ? BBK_KEYS_TILE : (W == 2 ? 4096 : 2048);  // 64 KB / 48 KB / 64 KB of LDS
     static constexpr int THREADS = BBK_KEYS_THREADS;
     static constexpr int ITEMS = TILE / THREADS;
 };
@@ -68,7 +68,7 @@ constexpr int kRdSlots = 1024;  // reads of one tile whose cursor tables fit LDS
 constexpr int kRdWords = 2048;  // packed read words of one tile staged in LDS (150 bp reads need ~330)
 template <int W>
 struct RdCfg {
-    static constexpr int CH = (W == 1) ? 8 : 4;
+    static constexpr int CH = (W == 1) ? 8 : (W == 2 ? 4 : 2);  // records of a tile: 64 KB (48 KB for 24-byte keys)
     static constexpr int TILE = kRdThreads * CH;
 };
 constexpr int kMaxBins = 1024;
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(HIST_ONLY ? kRdHistThreads : kRdThreads) void k_par
 
 static size_t part_reads_smem(int W, bool has_val, bool hist_only) {
     const size_t tables = sizeof(uint32_t) * 3 * (kRdSlots + 2) + sizeof(uint64_t) * (kRdWords + W + 2);
-    const size_t tile = (size_t)kRdThreads * (W == 1 ? 8 : 4);
+    const size_t tile = (size_t)kRdThreads * (W == 1 ? 8 : (W == 2 ? 4 : 2));
     const size_t stage = hist_only ? 0 : (size_t)W * 8 * tile + (has_val ? 4 * tile : 0);
     return sizeof(uint32_t) * (3 * 512 + 32) + std::max(tables, stage);
 }
@@ -1509,13 +1509,20 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
 // (32-bit ds_cmpst); a probe that finds a different index compares the two keys.  All keys are in
 // LDS before the first insertion, so there is no partially written slot to race with.
 constexpr int kHashIdxThreads = 512;
-constexpr int kHashIdxItems = 8;                        // 512 x 8 = 4096 records per bucket
-constexpr uint32_t kHashIdxCap = kHashIdxThreads * kHashIdxItems;
-constexpr uint32_t kHashIdxSlots = 8192;
+// 16-byte keys: 512 x 8 = 4096 records per bucket, 8192 slots; 24/32-byte keys: 512 x 4 = 2048 records, 4096 slots
+// (keys + table + payload table must fit the 160 KB of LDS)
+template <int W>
+struct HashIdxCfg {
+    static constexpr int ITEMS = (W <= 2) ? 8 : 4;
+    static constexpr uint32_t CAP = kHashIdxThreads * ITEMS;
+    static constexpr uint32_t SLOTS = 2 * CAP;
+};
 
 template <int W, int OP>
 __global__ __launch_bounds__(kHashIdxThreads) void k_bucket_hashidx(Key<W> *__restrict__ buf,
                                                                    uint32_t *__restrict__ vals, BucketArgs A) {
+    constexpr int kHashIdxItems = HashIdxCfg<W>::ITEMS;
+    constexpr uint32_t kHashIdxCap = HashIdxCfg<W>::CAP, kHashIdxSlots = HashIdxCfg<W>::SLOTS;
     constexpr bool IN_VAL = OP >= 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
@@ -1619,7 +1626,7 @@ __global__ __launch_bounds__(kHashIdxThreads) void k_bucket_hashidx(Key<W> *__re
 
 template <int W, int OP>
 static size_t bucket_hashidx_smem() {
-    return 4 * kHashIdxSlots + (OP != 0 ? 4 * kHashIdxSlots : 0) + 128 + (size_t)W * 8 * kHashIdxCap;
+    return 4 * HashIdxCfg<W>::SLOTS + (OP != 0 ? 4 * HashIdxCfg<W>::SLOTS : 0) + 128 + (size_t)W * 8 * HashIdxCfg<W>::CAP;
 }
 
 template <int OP>
@@ -1708,10 +1715,10 @@ struct BktCfg {
 #define BBK_BKT2_ITEMS 7
 #endif
     static constexpr int NT = (W == 1) ? BBK_BKT_NT : BBK_BKT2_NT;
-    static constexpr int ITEMS = (W == 1) ? BBK_BKT_ITEMS : BBK_BKT2_ITEMS;
+    static constexpr int ITEMS = (W == 1) ? BBK_BKT_ITEMS : (W == 2 ? BBK_BKT2_ITEMS : (W == 3 ? 5 : 3));
     static constexpr uint32_t CAP = NT * ITEMS;
     static constexpr int NT2 = 512;                               // second-chance kernel
-    static constexpr int ITEMS2 = (W == 1) ? 23 : 11;
+    static constexpr int ITEMS2 = (W == 1) ? 23 : (W == 2 ? 11 : (W == 3 ? 7 : 5));
     static constexpr uint32_t CAP2 = NT2 * ITEMS2;
 };
 // mean bucket = 0.70 CAP: a bucket holds ~100 distinct genomic k-mers x their multiplicity (~40 at 50x
@@ -1806,7 +1813,7 @@ struct MsdRunner {
     bool use_hashidx_dedup() const { return W >= 2 && dmode == MSD_HASH; }
     // records a first-pass bucket kernel can hold
     uint32_t bucket_cap() const {
-        if (use_hashidx_dedup()) return kHashIdxCap;
+        if (use_hashidx_dedup()) return HashIdxCfg<W>::CAP;
         if (use_hash_dedup()) return (uint32_t)(kHashThreads * kHashItems);
         return BktCfg<W>::CAP;
     }
@@ -2444,7 +2451,15 @@ bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_read
         MsdRunner<2> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
         return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
-    return false;  // wider keys stay on the LSD path for now
+    if (W == 3) {
+        MsdRunner<3> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
+        return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
+    }
+    if (W == 4) {
+        MsdRunner<4> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
+        return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
+    }
+    return false;
 }
 
 }  // namespace bbk
