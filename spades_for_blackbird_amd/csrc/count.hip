@@ -528,11 +528,6 @@ static void export_ordered(bbk_ctx *ctx, const bbk_kmerset *s, const PassDesc *p
         BBK_HIP(hipStreamSynchronize(ctx->stream));
         return;
     }
-    if (h_counts) {
-        uint64_t hc[256];
-        digit_histogram(ctx, (int)s->W, s->keys.p, s->n, *pd, hc);
-        for (unsigned i = 0; i < pd->nb; ++i) h_counts[i] = hc[i];
-    }
     // One stable pass on the bucket digit keeps the ascending order inside each bucket.  It reads the set
     // and writes straight into the caller's buffer when that is device memory (no staging copies).
     const bool kdev = is_device_ptr(dst_keys), cdev = !wc || is_device_ptr(dst_counts);
@@ -541,7 +536,11 @@ static void export_ordered(bbk_ctx *ctx, const bbk_kmerset *s, const PassDesc *p
     if (wc && !cdev) tc.alloc(s->n * 4);
     void *ok = kdev ? dst_keys : tk.p;
     uint32_t *oc = wc ? (cdev ? (uint32_t *)dst_counts : tc.as<uint32_t>()) : nullptr;
-    partition_records(ctx, (int)s->W, s->keys.p, ok, wc ? s->counts.as<uint32_t>() : nullptr, oc, s->n, *pd);
+    uint64_t hc[256];  // the pass counts the digit values anyway: the per-owner counts come for free
+    partition_records(ctx, (int)s->W, s->keys.p, ok, wc ? s->counts.as<uint32_t>() : nullptr, oc, s->n, *pd,
+                      h_counts ? hc : nullptr);
+    if (h_counts)
+        for (unsigned i = 0; i < pd->nb; ++i) h_counts[i] = hc[i];
     if (!kdev) BBK_HIP(hipMemcpyAsync(dst_keys, tk.p, s->n * rec, hipMemcpyDeviceToHost, ctx->stream));
     if (wc && !cdev) BBK_HIP(hipMemcpyAsync(dst_counts, tc.p, s->n * 4, hipMemcpyDeviceToHost, ctx->stream));
     BBK_HIP(hipStreamSynchronize(ctx->stream));

@@ -436,7 +436,7 @@ std::vector<PassDesc> key_passes(unsigned k) {
 // one stable counting pass src -> dst on the digit `pd` (hist/chunk: scratch of the caller)
 template <int W>
 static void sort_pass(bbk_ctx *ctx, const Key<W> *src, Key<W> *dst, const uint32_t *vsrc, uint32_t *vdst, uint64_t n,
-                      const PassDesc &pd, DevBuf &hist, DevBuf &chunk) {
+                      const PassDesc &pd, DevBuf &hist, DevBuf &chunk, uint64_t *d_digit_totals = nullptr) {
     constexpr int TILE = SortCfg<W>::TILE;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     const uint64_t nchunks = (ntiles + kChunk - 1) / kChunk;
@@ -454,7 +454,7 @@ static void sort_pass(bbk_ctx *ctx, const Key<W> *src, Key<W> *dst, const uint32
         hipLaunchKernelGGL(k_colsum, dim3((unsigned)nchunks), dim3(kRadix), 0, ctx->stream, hist.as<uint32_t>(), ntiles,
                            chunk.as<uint64_t>());
         hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kRadix), 0, ctx->stream, chunk.as<uint64_t>(), nchunks,
-                           (uint64_t *)nullptr);
+                           d_digit_totals);
         hipLaunchKernelGGL(k_tile_offsets, dim3((unsigned)nchunks), dim3(kRadix), 0, ctx->stream, hist.as<uint32_t>(),
                            ntiles, chunk.as<uint64_t>());
         check_launch("scan kernels");
@@ -513,22 +513,26 @@ static void sort_impl(bbk_ctx *ctx, Key<W> *keys, Key<W> *tmp, uint32_t *vals, u
 
 template <int W>
 static void partition_impl(bbk_ctx *ctx, const Key<W> *src, Key<W> *dst, const uint32_t *vsrc, uint32_t *vdst, uint64_t n,
-                           const PassDesc &pd) {
+                           const PassDesc &pd, uint64_t *h_digit_totals) {
+    if (h_digit_totals) memset(h_digit_totals, 0, kRadix * sizeof(uint64_t));
     if (n == 0) return;
-    DevBuf hist, chunk;
+    DevBuf hist, chunk, tot;
     sort_scratch<W>(n, vsrc != nullptr, hist, chunk);
-    sort_pass<W>(ctx, src, dst, vsrc, vdst, n, pd, hist, chunk);
+    if (h_digit_totals) tot.alloc(kRadix * sizeof(uint64_t));
+    sort_pass<W>(ctx, src, dst, vsrc, vdst, n, pd, hist, chunk, h_digit_totals ? tot.as<uint64_t>() : nullptr);
+    if (h_digit_totals)
+        BBK_HIP(hipMemcpyAsync(h_digit_totals, tot.p, kRadix * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     BBK_HIP(hipStreamSynchronize(ctx->stream));
 }
 
 // one stable pass src -> dst (both on the device, not aliased): records ordered by the digit, input order kept inside
 void partition_records(bbk_ctx *ctx, int W, const void *src, void *dst, const uint32_t *vsrc, uint32_t *vdst, uint64_t n,
-                       const PassDesc &pd) {
+                       const PassDesc &pd, uint64_t *h_digit_totals) {
     switch (W) {
-        case 1: partition_impl<1>(ctx, (const Key<1> *)src, (Key<1> *)dst, vsrc, vdst, n, pd); break;
-        case 2: partition_impl<2>(ctx, (const Key<2> *)src, (Key<2> *)dst, vsrc, vdst, n, pd); break;
-        case 3: partition_impl<3>(ctx, (const Key<3> *)src, (Key<3> *)dst, vsrc, vdst, n, pd); break;
-        case 4: partition_impl<4>(ctx, (const Key<4> *)src, (Key<4> *)dst, vsrc, vdst, n, pd); break;
+        case 1: partition_impl<1>(ctx, (const Key<1> *)src, (Key<1> *)dst, vsrc, vdst, n, pd, h_digit_totals); break;
+        case 2: partition_impl<2>(ctx, (const Key<2> *)src, (Key<2> *)dst, vsrc, vdst, n, pd, h_digit_totals); break;
+        case 3: partition_impl<3>(ctx, (const Key<3> *)src, (Key<3> *)dst, vsrc, vdst, n, pd, h_digit_totals); break;
+        case 4: partition_impl<4>(ctx, (const Key<4> *)src, (Key<4> *)dst, vsrc, vdst, n, pd, h_digit_totals); break;
         default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %d", W);
     }
 }
