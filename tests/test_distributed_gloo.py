@@ -44,7 +44,7 @@ def _worker(rank, world, port, k, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,world", [(21, 2), (33, 2), (21, 3)])
+@pytest.mark.parametrize("k,world", [(21, 2), (33, 2), (21, 3), (21, 8)])
 def test_multi_rank_exchange(k, world):
     """world 3 also covers the rank whose own segment sits in the middle of its send buffer."""
     from oracle import oracle as O
