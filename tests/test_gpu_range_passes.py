@@ -85,6 +85,7 @@ def test_forced_slot_mode_with_overflow():
     oracle bit for bit (both-strand set with counts, reference order, unsorted canonical set, extension index)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BBK_SLOTS_MIN="0", BBK_VERBOSE="1")
+    env.pop("BBK_NO_SLOTS", None)  # this test is about the slot mode
     r = subprocess.run([sys.executable, "-c", SLOT_SCRIPT % {"root": root}], capture_output=True, text=True, env=env,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
