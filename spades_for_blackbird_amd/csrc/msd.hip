@@ -2218,8 +2218,9 @@ struct MsdRunner {
             }
             if (n_extra) {
                 // every record of the affected keys: the spill list, the overflowing segments' and buckets' slots
+                const bool tiny = n_extra <= (uint64_t)BktCfg<W>::CAP2;  // fits one workgroup of the radix kernel
                 DevBuf ek(n_extra * rec), ev;
-                if (has_val) ev.alloc(n_extra * 4);
+                if (has_val || (tiny && op != MSD_OP_NONE)) ev.alloc(n_extra * 4 + 16);
                 uint64_t o = 0;
                 auto put = [&](const void *ksrc, const uint32_t *vsrc, uint64_t first, uint64_t cnt) {
                     if (!cnt) return;
@@ -2233,6 +2234,27 @@ struct MsdRunner {
                 put(spill_k.p, spill_v.as<uint32_t>(), 0, n_spill);
                 for (uint32_t b : over_seg) put(bufA.p, valA.as<uint32_t>(), (uint64_t)b * seg_cap, seg_cap);
                 for (uint32_t b : over_bkt) put(bufB.p, valB.as<uint32_t>(), (uint64_t)b * stride2, cap2);
+                if (tiny) {
+                    // the usual case (one or two crowded buckets): ONE workgroup sorts + reduces all of it in LDS,
+                    // instead of a whole partition pipeline for a few thousand records
+                    DevBuf tb(16), tc(16);
+                    const uint32_t hbo[2] = {0u, (uint32_t)n_extra};
+                    BBK_HIP(hipMemcpyAsync(tb.p, hbo, 8, hipMemcpyHostToDevice, ctx->stream));
+                    BucketArgs At{tb.as<uint32_t>(), tc.as<uint32_t>(), nullptr, (int)k, nullptr, 0u, 0u,
+                                  nullptr, nullptr, nullptr, nullptr};
+                    MsdRunner<W> sorter = *this;
+                    sorter.dmode = MSD_KEYS;  // picks the sorting kernels in bucket_dispatch
+                    sorter.template bucket_dispatch<true>(1u, ek.as<Key<W>>(), ev.as<uint32_t>(), At,
+                                                          (double)n_extra * (rec + (has_val ? 4 : 0)),
+                                                          /*allow_hash=*/false);
+                    uint32_t d = 0;
+                    BBK_HIP(hipMemcpyAsync(&d, tc.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+                    BBK_HIP(hipStreamSynchronize(ctx->stream));
+                    BBK_REQUIRE(d != 0xFFFFFFFFu && d <= n_extra, BBK_ERR_INTERNAL, "overflow pass: bad count");
+                    extra.n = d;
+                    extra.keys = std::move(ek);
+                    if (op != MSD_OP_NONE) extra.vals = std::move(ev);
+                } else {
                 BBK_HIP(hipStreamSynchronize(ctx->stream));
                 // The records were selected BY their hash bucket, so the same hash would pile them up again:
                 // partition them by key instead (the order of the result does not matter), and never decline --
@@ -2244,6 +2266,7 @@ struct MsdRunner {
                 // declined (e.g. one k-mer makes up most of it): so does this call, the caller takes the LSD path
                 if (!exact.run_all(nullptr, ek.p, has_val ? ev.as<uint32_t>() : nullptr, n_extra, false, extra)) return 0;
                 extra.bucket_off.release();
+                }
             }
             novf = over_bkt.size() + over_seg.size();
         }
