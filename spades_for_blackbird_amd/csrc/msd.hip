@@ -1391,8 +1391,15 @@ static size_t bucket_smem() {
 // ~30 instructions per record instead of 6 radix passes.  The distinct keys (+ reduced payload)
 // are written back in place in table order.
 constexpr int kHashThreads = 512;
-constexpr int kHashItems = 12;                      // 512 x 12 = 6144 records
-constexpr uint32_t kHashSlots = 8192;               // load factor <= 0.75 even if every record is distinct
+#ifndef BBK_HASH_ITEMS
+#define BBK_HASH_ITEMS 16
+#endif
+constexpr int kHashItems = BBK_HASH_ITEMS;          // 512 x 16 = 8192 records per bucket (x 12: 2 % slower, and the
+                                                    // fullest bucket of a 10 M-read batch then overflows its slot)
+constexpr uint32_t kHashSlots = 8192;               // distinct keys of a bucket: ~n / multiplicity, far below the slots
+                                                    // for read data; all-distinct input fills ~0.7 of them
+constexpr uint32_t kHashMaxProbes = 256;            // a probe sequence this long means the table is (nearly) full: the
+                                                    // bucket holds more distinct keys than slots -> left to the caller
 
 template <int OP>
 __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict__ buf, uint32_t *__restrict__ vals,
@@ -1422,6 +1429,7 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
         tab[s] = EMPTY;
         if (OP != 0) pay[s] = 0;
     }
+    if (tid == 0) scan_tmp[14] = 0;
     __syncthreads();
     BBK_PH(4, 0, t_prev);  // table init
     uint64_t kk[kHashItems];
@@ -1447,10 +1455,15 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
             h *= 0x9E3779B1u;
             uint32_t slot = (h >> 19) & (kHashSlots - 1);
             // (probing all records of a lane in rounds, 12 ds_cmpst in flight, was measured 15 % slower)
+            uint32_t probes = 0;
             for (;;) {
                 const unsigned long long old = atomicCAS(&tab[slot], EMPTY, (unsigned long long)kk[i]);
                 if (old == EMPTY || old == kk[i]) break;
                 slot = (slot + 1) & (kHashSlots - 1);
+                if (kHashItems * kHashThreads > (int)(kHashSlots * 3 / 4) && ++probes > kHashMaxProbes) {
+                    scan_tmp[14] = 1;  // give up on this bucket (benign race: everyone writes 1)
+                    break;
+                }
             }
             if (OP == 1) atomicAdd(&pay[slot], 1u);
             else if (OP == 2) atomicAdd(&pay[slot], vv[i]);
@@ -1458,6 +1471,10 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
         }
     }
     __syncthreads();
+    if (scan_tmp[14]) {  // more distinct keys than the table takes: nothing has been written, the caller takes over
+        if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
+        return;
+    }
     BBK_PH(4, 1, t_prev);  // loads + insert
     // compaction of the occupied slots: thread t owns slots t, t + 512, ... (consecutive lanes read
     // consecutive 8-byte slots: no LDS bank conflicts; the output order is free, the set is unsorted)
@@ -1920,7 +1937,10 @@ struct MsdRunner {
                     (unsigned long long)N, sel_bits ? " in one of 256 hash ranges" : "");
 
         // ---- bin plan: nb1 (power of two) level-1 bins; level-2 bin counts are chosen per segment below
-        const double target = kBucketFill * bucket_cap();
+        // key arrays deduplicated through the LDS hash table (merge of received shards: multiplicity 1..nranks) are
+        // nearly all distinct: keep the table's load around 0.5 there
+        const double fill = (!from_reads && use_hash_dedup()) ? 0.52 : kBucketFill;
+        const double target = fill * bucket_cap();
         const double want = std::max(1.0, std::ceil((double)N / target));
         uint32_t nb1 = 1;
         int b1 = 0;
@@ -1976,7 +1996,7 @@ struct MsdRunner {
         const char *smin = getenv("BBK_SLOTS_MIN");  // tests lower it to run the slot mode on small inputs
         const uint64_t slots_min = smin ? strtoull(smin, nullptr, 10) : (1ull << 22);
         const bool slots = slots_ok && dmode == MSD_HASH && (use_hash_dedup() || use_hashidx_dedup()) && nb1 > 1 &&
-                           N >= slots_min && (double)N / kBucketFill * 1.1 + (double)N < 4.2e9;  // u32 slot offsets
+                           N >= slots_min && (double)N / fill * 1.1 + (double)N < 4.2e9;  // u32 slot offsets
         const uint32_t seg_cap = slots ? ((uint32_t)((double)N / nb1 * 1.01) + 8192u) | 1u : 0u;
         const uint32_t cap2 = bucket_cap();
         // bucket slots 256 B further apart than their capacity: with a power-of-two-ish stride every bucket's
