@@ -210,7 +210,6 @@ std::vector<PassDesc> key_passes(unsigned k);
 void sort_records(bbk_ctx *ctx, int W, void *keys, void *keys_tmp, uint32_t *vals, uint32_t *vals_tmp, uint64_t n,
                   const std::vector<PassDesc> &passes);
 // Per-bin record counts of one pass (256 bins, written to h_counts), e.g. bucket sizes.
-void digit_histogram(bbk_ctx *ctx, int W, const void *keys, uint64_t n, PassDesc pd, uint64_t *h_counts);
 // one stable counting pass src -> dst (device buffers, not aliased) on the digit `pd`; h_digit_totals (256 entries,
 // optional) receives the number of records of every digit value
 void partition_records(bbk_ctx *ctx, int W, const void *src, void *dst, const uint32_t *vsrc, uint32_t *vdst, uint64_t n,

@@ -548,37 +548,6 @@ void sort_records(bbk_ctx *ctx, int W, void *keys, void *keys_tmp, uint32_t *val
     }
 }
 
-template <int W>
-static void digit_hist_impl(bbk_ctx *ctx, const Key<W> *keys, uint64_t n, PassDesc pd, uint64_t *h_counts) {
-    memset(h_counts, 0, kRadix * sizeof(uint64_t));
-    if (n == 0) return;
-    constexpr int TILE = SortCfg<W>::TILE;
-    const uint64_t ntiles = (n + TILE - 1) / TILE;
-    const uint64_t nchunks = (ntiles + kChunk - 1) / kChunk;
-    DevBuf hist(ntiles * kRadix * sizeof(uint32_t));
-    DevBuf chunk(nchunks * kRadix * sizeof(uint64_t));
-    DevBuf tot(kRadix * sizeof(uint64_t));
-    hipLaunchKernelGGL(k_hist<W>, dim3((unsigned)ntiles), dim3(kThreads), 0, ctx->stream, keys, n, pd,
-                       hist.as<uint32_t>());
-    hipLaunchKernelGGL(k_colsum, dim3((unsigned)nchunks), dim3(kRadix), 0, ctx->stream, hist.as<uint32_t>(), ntiles,
-                       chunk.as<uint64_t>());
-    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(kRadix), 0, ctx->stream, chunk.as<uint64_t>(), nchunks,
-                       tot.as<uint64_t>());
-    check_launch("digit_histogram");
-    BBK_HIP(hipMemcpyAsync(h_counts, tot.p, kRadix * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    BBK_HIP(hipStreamSynchronize(ctx->stream));
-}
-
-void digit_histogram(bbk_ctx *ctx, int W, const void *keys, uint64_t n, PassDesc pd, uint64_t *h_counts) {
-    switch (W) {
-        case 1: digit_hist_impl<1>(ctx, (const Key<1> *)keys, n, pd, h_counts); break;
-        case 2: digit_hist_impl<2>(ctx, (const Key<2> *)keys, n, pd, h_counts); break;
-        case 3: digit_hist_impl<3>(ctx, (const Key<3> *)keys, n, pd, h_counts); break;
-        case 4: digit_hist_impl<4>(ctx, (const Key<4> *)keys, n, pd, h_counts); break;
-        default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %d", W);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // unique / reduce-by-key on a sorted array
 // ------------------------------------------------------------------------------------------
