@@ -357,3 +357,45 @@ def test_median_multiplicity_read_filter(ctx, k):
         assert 0 < int(got.sum()) < len(reads)
     with pytest.raises(B.BBKError):
         ctx.median_filter(r, ctx.count(r, k, B.BOTH_STRANDS | B.WITH_COUNTS), 2)  # needs the canonical set
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[1] at full size (10 M x 150 bp, k=21: 2.6 G k-mer instances), checked through
+    size-independent properties on the device: strictly ascending = distinct, multiplicities add up to the instance
+    count, the set is closed under reverse complement (sample), the reference-order set is the same multiset with
+    ascending XXH3 buckets (sample), and the sharded building blocks (unsorted canonical set) agree in size."""
+    import torch
+    ctx = B.Context(0, stream=torch.cuda.current_stream())
+    k, n_reads, L = 21, 10_000_000, 150
+    r = ctx.reads_synth(n_reads, read_len=L, genome_len=n_reads * L // 50, seed_genome=42, seed_reads=43)
+    s = ctx.count(r, k, B.BOTH_STRANDS | B.WITH_COUNTS)
+    n = len(s)
+    assert s.instances == 2 * n_reads * (L - k + 1)
+    keys = torch.empty((n, 1), dtype=torch.int64, device="cuda")
+    cnt = torch.empty(n, dtype=torch.int32, device="cuda")
+    s.export_to(keys, B.ORDER_SORTED, cnt)
+    kv = keys.view(-1)
+    assert bool(torch.all(kv[1:] > kv[:-1]))                       # 42-bit keys: int64 order == uint64 order
+    assert int(cnt.sum(dtype=torch.int64).item()) == s.instances   # every instance counted once
+    assert int(cnt.min().item()) >= 1
+    ref = ctx.count(r, k, B.BOTH_STRANDS | B.REFERENCE_ORDER)
+    assert len(ref) == n
+    rk = torch.empty((n, 1), dtype=torch.int64, device="cuda")
+    ref.export_to(rk, B.ORDER_REFERENCE_BUCKETS16)
+    assert bool(torch.equal(torch.sort(rk.view(-1)).values, kv))    # same multiset
+    step = max(1, n // 4000)
+    sample = rk.view(-1)[::step].cpu().numpy().view(np.uint64)
+    b = [O.bucket(np.array([x], dtype=np.uint64), 16) for x in sample]
+    assert b == sorted(b) and b[0] == 0 and b[-1] == 15
+    # closure under reverse complement on a sample (binary search on the device-sorted keys)
+    samp = kv[:: max(1, n // 2000)].cpu().numpy().view(np.uint64)
+    rcs = []
+    for x in samp:
+        s_ = "".join("ACGT"[(int(x) >> (2 * i)) & 3] for i in range(k))
+        rcs.append(O.kmer_words(rc(s_))[0])
+    q = torch.from_numpy(np.array(rcs, dtype=np.uint64).view(np.int64)).cuda()
+    pos = torch.searchsorted(kv, q)
+    assert bool(torch.all(kv[pos.clamp(max=n - 1)] == q))
+    u = ctx.count(r, k, B.CANONICAL | B.UNSORTED)
+    assert 2 * len(u) == n                                           # odd k: no self-reverse-complementary k-mers
+    ctx.close()
