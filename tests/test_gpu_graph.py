@@ -304,3 +304,32 @@ def test_early_tip_clipping(ctx, k, bound):
     # if no new tips arose; the reference makes no such promise, so just check it runs and stays consistent
     removed2, links2 = x.clip_tips(bound)
     assert removed2 >= 0 and links2 >= 0
+
+
+def test_full_size_graph_properties():
+    """The gbuilder path at the full configs[1] size (10 M x 150 bp, k=21) through size-independent properties:
+    the extension index holds exactly the canonical k-mers of the reads; the unitigs partition the (k+1)-mer set --
+    sum(len - k) over the kept unitigs equals the number of canonical (k+1)-mer classes, plus the classes that a
+    self-reverse-complementary unitig (one around each palindromic (k+1)-mer) covers twice, a handful at this size;
+    coverage: the KC values add up to the (k+1)-mer instance count (every instance lies on exactly one unitig edge,
+    self-conjugate unitigs aside)."""
+    import torch
+    ctx = B.Context(0, stream=torch.cuda.current_stream())
+    k, n_reads, L = 21, 10_000_000, 150
+    r = ctx.reads_synth(n_reads, read_len=L, genome_len=n_reads * L // 50, seed_genome=42, seed_reads=43)
+    x = ctx.extindex(r, k)
+    canon_k = ctx.count(r, k, B.CANONICAL | B.UNSORTED)
+    assert len(x) == len(canon_k)                      # every read is longer than k: each k-mer has an edge
+    canon_k1 = ctx.count(r, k + 1, B.CANONICAL | B.WITH_COUNTS)
+    u = ctx.unitigs(x)
+    assert u.n_loops == 0 or u.n_loops < 10
+    edges = u.total_bases - len(u) * k                 # sum(len - k)
+    extra = edges - len(canon_k1)
+    assert 0 <= extra < 1e-5 * len(canon_k1), (edges, len(canon_k1))
+    assert u.n_vertices > 0 and u.n_links > 0 and u.n_links < 8 * len(u)
+    u.add_coverage(r)
+    kc = np.asarray(u.kc(), dtype=np.uint64)
+    inst = n_reads * (L - k)                           # (k+1)-mer instances of the reads
+    total = int(kc.sum())
+    assert inst <= total < inst * (1 + 1e-5)           # self-conjugate unitigs count their instances on both strands
+    ctx.close()
