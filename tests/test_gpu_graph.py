@@ -306,8 +306,10 @@ def test_early_tip_clipping(ctx, k, bound):
     assert removed2 >= 0 and links2 >= 0
 
 
-def test_full_size_graph_properties():
-    """The gbuilder path at the full configs[1] size (10 M x 150 bp, k=21) through size-independent properties:
+@pytest.mark.parametrize("k,n_reads", [(21, 10_000_000), (55, 4_000_000), (77, 2_000_000)])
+def test_full_size_graph_properties(k, n_reads):
+    """The gbuilder path at the full configs[1] size (10 M x 150 bp, k=21; 16- and 24-byte keys at 4 M / 2 M reads)
+    through size-independent properties:
     the extension index holds exactly the canonical k-mers of the reads; the unitigs partition the (k+1)-mer set --
     sum(len - k) over the kept unitigs equals the number of canonical (k+1)-mer classes, plus the classes that a
     self-reverse-complementary unitig (one around each palindromic (k+1)-mer) covers twice, a handful at this size;
@@ -315,7 +317,7 @@ def test_full_size_graph_properties():
     self-conjugate unitigs aside)."""
     import torch
     ctx = B.Context(0, stream=torch.cuda.current_stream())
-    k, n_reads, L = 21, 10_000_000, 150
+    L = 150
     r = ctx.reads_synth(n_reads, read_len=L, genome_len=n_reads * L // 50, seed_genome=42, seed_reads=43)
     x = ctx.extindex(r, k)
     canon_k = ctx.count(r, k, B.CANONICAL | B.UNSORTED)
