@@ -271,7 +271,8 @@ static void expand_both_strands(bbk_ctx *ctx, unsigned k, const DevBuf &ck, cons
             // partitions them into the final_kmers order directly, at the price of the hash in every level
             const bool ref_prefix = want_ref && !tag && W <= 2;  // 8-byte keys without room for the tag (k = 31, 32) too
             if (msd_sort_reduce(ctx, k, ref_prefix ? MSD_REF : MSD_KEYS, wc ? MSD_OP_SUM : MSD_OP_NONE, nullptr, e.p,
-                                wc ? ec.as<uint32_t>() : nullptr, 2 * D, false, m, tag ? 4u : 0u)) {
+                                wc ? ec.as<uint32_t>() : nullptr, 2 * D, false, m, tag ? 4u : 0u,
+                                /*assume_distinct: odd k has no self-reverse-complementary k-mers*/ (k & 1) != 0)) {
                 s.n = m.n;
                 s.keys = std::move(m.keys);
                 if (wc) s.counts = std::move(m.vals);

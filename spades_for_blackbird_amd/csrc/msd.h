@@ -26,6 +26,9 @@ struct MsdOutput {
 // that is more significant than the k-mer (the caller put it there); the records are ordered by
 // (tag, k-mer) and the tag is cleared in the output.
 bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_reads *rd, const void *d_keys,
-                     const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out, unsigned tag_bits = 0);
+                     const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out, unsigned tag_bits = 0,
+                     bool assume_distinct = false);
+// assume_distinct (key array, KEYS / REF prefix): the caller expects no duplicates, so the sorted result is written
+// directly at the offsets of the input (no compaction pass); verified on the fly, redone in place otherwise.
 
 }  // namespace bbk

@@ -823,6 +823,13 @@ struct BucketArgs {
     void *out_keys;
     uint32_t *out_vals;
     uint32_t *out_total;
+    // sorting kernels, input known to hold (almost certainly) no duplicates: bucket b's records go straight to
+    // sorted_keys[boff[b] ...] (the dense result: same offsets as the input when nothing is removed), word 0 masked
+    // with strip_mask; a bucket that did remove a duplicate raises *dup_flag and the caller redoes the pass in place
+    void *sorted_keys;
+    uint32_t *sorted_vals;
+    uint32_t *dup_flag;
+    uint64_t strip_mask;
 };
 
 // first record and record count of bucket b (count 0xFFFFFFFF: the slot overflowed)
@@ -910,7 +917,13 @@ __device__ __forceinline__ void bucket_reduce(Key<W> *skeys, uint32_t *svals, ui
                     }
                     ++seg;
                     a = 0;
-                    key_store<W>(&buf[start + (uint32_t)seg], mine[i]);  // distinct keys, in place
+                    if (A.sorted_keys) {
+                        Key<W> kx = mine[i];
+                        kx.w[0] &= A.strip_mask;
+                        key_store<W>(&reinterpret_cast<Key<W> *>(A.sorted_keys)[start + (uint32_t)seg], kx);
+                    } else {
+                        key_store<W>(&buf[start + (uint32_t)seg], mine[i]);  // distinct keys, in place
+                    }
                 }
                 any = true;
                 if (OP == 1) a += 1;
@@ -925,8 +938,10 @@ __device__ __forceinline__ void bucket_reduce(Key<W> *skeys, uint32_t *svals, ui
     }
     if (OP != 0) {
         __syncthreads();
-        for (uint32_t s = tid; s < total; s += NT) vals[start + s] = acc[s];
+        uint32_t *vdst = A.sorted_keys ? A.sorted_vals : vals;
+        for (uint32_t s = tid; s < total; s += NT) vdst[start + s] = acc[s];
     }
+    if (tid == 0 && A.sorted_keys && total != n) atomicOr(A.dup_flag, 1u);
     if (tid == 0) A.dcount[b] = total;
 }
 
@@ -1752,6 +1767,7 @@ struct MsdRunner {
     uint64_t strip_mask = ~0ull;  // tagged sort: bits of word 0 that survive in the output
     bool slots_ok = getenv("BBK_NO_SLOTS") == nullptr;  // histogram-free slot mode allowed (HASH prefix)
     bool never_decline = false;  // finish whatever overflows bucket by bucket on the LSD path instead of declining
+    bool assume_distinct = false;  // caller's hint (key arrays, KEYS / REF prefix): duplicates are not expected
 
     template <bool HAS_VAL, bool HIST>
     void launch_part(const char *fam, double bytes, uint32_t ntiles, const Key<W> *in, const uint32_t *vin, TileMap M,
@@ -2177,8 +2193,26 @@ struct MsdRunner {
         }
         BucketArgs A{boff.as<uint32_t>(), dcount.as<uint32_t>(), nullptr, (int)k, verbose ? dbg.as<uint32_t>() : nullptr,
                      slots ? cap2 : 0u, slots ? stride2 : 0u, hist2.as<uint32_t>(), slots ? out.keys.p : nullptr,
-                     slots ? out.vals.as<uint32_t>() : nullptr, slots ? spill_n.as<uint32_t>() + 1 : nullptr};
+                     slots ? out.vals.as<uint32_t>() : nullptr, slots ? spill_n.as<uint32_t>() + 1 : nullptr,
+                     nullptr, nullptr, nullptr, ~0ull};
         const double bb = (double)N * (rec + (has_val ? 4 : 0));
+        // Sorted output of a key array that should hold no duplicates (both strands of a distinct canonical set, odd
+        // k): the dense result has the offsets of the input, so the sorting kernels write it directly -- no
+        // compaction pass.  Should a bucket remove a duplicate after all, or be left to the second chance, the pass
+        // is redone in place (the direct pass does not touch the buckets).
+        const bool direct = !slots && assume_distinct && (dmode == MSD_KEYS || dmode == MSD_REF) &&
+                            getenv("BBK_NO_DIRECT") == nullptr;
+        DevBuf dupf;
+        if (direct) {
+            out.keys.alloc(N * rec + 16);
+            if (out_vals) out.vals.alloc(N * 4 + 16);
+            dupf.alloc(16);
+            BBK_HIP(hipMemsetAsync(dupf.p, 0, 16, ctx->stream));
+            A.sorted_keys = out.keys.p;
+            A.sorted_vals = out.vals.as<uint32_t>();
+            A.dup_flag = dupf.as<uint32_t>();
+            A.strip_mask = strip_mask;
+        }
         bucket_dispatch<false>(nbuckets, bufB.as<Key<W>>(), valB.as<uint32_t>(), A, bb);
 
         // buckets the first pass left alone: listed on the device, only the (short) list comes to the host
@@ -2189,16 +2223,37 @@ struct MsdRunner {
             d_flag_n = spill_n.as<uint32_t>() + 2;
         } else {
             flag_n.alloc(16);
-            BBK_HIP(hipMemsetAsync(flag_n.p, 0, 16, ctx->stream));
             d_flag_n = flag_n.as<uint32_t>();
         }
-        hipLaunchKernelGGL(k_flagged, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream, dcount.as<uint32_t>(),
-                           nbuckets, flag_ids.as<uint32_t>(), kFlagCap, d_flag_n);
-        check_launch("k_flagged");
-        uint32_t ctr[4] = {0, 0, 0, 0};  // spilled, direct, flagged
-        if (slots) BBK_HIP(hipMemcpyAsync(ctr, spill_n.p, 12, hipMemcpyDeviceToHost, ctx->stream));
-        else BBK_HIP(hipMemcpyAsync(ctr + 2, flag_n.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        uint32_t ctr[4] = {0, 0, 0, 0};  // spilled, direct, flagged, duplicates seen by the direct pass
+        auto fetch_flags = [&]() {
+            if (!slots) BBK_HIP(hipMemsetAsync(flag_n.p, 0, 16, ctx->stream));
+            hipLaunchKernelGGL(k_flagged, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream, dcount.as<uint32_t>(),
+                               nbuckets, flag_ids.as<uint32_t>(), kFlagCap, d_flag_n);
+            check_launch("k_flagged");
+            if (slots) BBK_HIP(hipMemcpyAsync(ctr, spill_n.p, 12, hipMemcpyDeviceToHost, ctx->stream));
+            else BBK_HIP(hipMemcpyAsync(ctr + 2, flag_n.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            if (direct) BBK_HIP(hipMemcpyAsync(ctr + 3, dupf.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+        };
+        fetch_flags();
+        if (direct) {
+            if (ctr[2] == 0 && ctr[3] == 0) {  // every bucket sorted, nothing removed: the result is complete
+                out.n = N;
+                out.nbuckets = 0;
+                out.overflow_buckets = 0;
+                return 1;
+            }
+            if (verbose) fprintf(stderr, "[bbk] msd direct output withdrawn (flagged=%u dup=%u): in-place pass\n", ctr[2], ctr[3]);
+            out.keys.release();
+            out.vals.release();
+            A.sorted_keys = nullptr;
+            A.sorted_vals = nullptr;
+            A.dup_flag = nullptr;
+            A.strip_mask = ~0ull;
+            bucket_dispatch<false>(nbuckets, bufB.as<Key<W>>(), valB.as<uint32_t>(), A, bb);
+            fetch_flags();
+        }
         const uint32_t n_spill = ctr[0], n_direct = ctr[1], n_flag = ctr[2];
         if (n_flag > kFlagCap) {  // tens of thousands of overflowing buckets: not an input for this path
             if (verbose) fprintf(stderr, "[bbk] msd: %u buckets overflow\n", n_flag);
@@ -2261,7 +2316,7 @@ struct MsdRunner {
                     const uint32_t hbo[2] = {0u, (uint32_t)n_extra};
                     BBK_HIP(hipMemcpyAsync(tb.p, hbo, 8, hipMemcpyHostToDevice, ctx->stream));
                     BucketArgs At{tb.as<uint32_t>(), tc.as<uint32_t>(), nullptr, (int)k, nullptr, 0u, 0u,
-                                  nullptr, nullptr, nullptr, nullptr};
+                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull};
                     MsdRunner<W> sorter = *this;
                     sorter.dmode = MSD_KEYS;  // picks the sorting kernels in bucket_dispatch
                     sorter.template bucket_dispatch<true>(1u, ek.as<Key<W>>(), ev.as<uint32_t>(), At,
@@ -2311,7 +2366,7 @@ struct MsdRunner {
                 DevBuf ids(big.size() * 4);
                 BBK_HIP(hipMemcpyAsync(ids.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, ctx->stream));
                 BucketArgs A2{boff.as<uint32_t>(), dcount.as<uint32_t>(), ids.as<uint32_t>(), (int)k, nullptr, 0u, 0u,
-                              nullptr, nullptr, nullptr, nullptr};
+                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull};
                 const double b2 = (double)big_rec * (rec + (has_val ? 4 : 0));
                 bucket_dispatch<true>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2,
                                       /*allow_hash=*/false);
@@ -2470,7 +2525,8 @@ static void dump_phases() {
 #endif
 
 bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_reads *rd, const void *d_keys,
-                     const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out, unsigned tag_bits) {
+                     const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out, unsigned tag_bits,
+                     bool assume_distinct) {
     const int W = (int)words_of(k);
     if (tag_bits) {
         // the tag sits right above the k-mer (bits [2k, 2k + tag_bits)): sort as a (k + tag_bits/2)-mer, clear the
@@ -2479,6 +2535,7 @@ bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_read
                     BBK_ERR_INTERNAL, "tagged sort needs 8-byte keys with %u spare bits", tag_bits);
         MsdRunner<1> r{ctx, k + tag_bits / 2, dmode, op, d_vals != nullptr};
         r.strip_mask = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+        r.assume_distinct = assume_distinct;
         return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
 #ifdef BBK_PHASE_PROF
@@ -2488,18 +2545,22 @@ bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_read
 #endif
     if (W == 1) {
         MsdRunner<1> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
+        r.assume_distinct = assume_distinct;
         return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
     if (W == 2) {
         MsdRunner<2> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
+        r.assume_distinct = assume_distinct;
         return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
     if (W == 3) {
         MsdRunner<3> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
+        r.assume_distinct = assume_distinct;
         return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
     if (W == 4) {
         MsdRunner<4> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
+        r.assume_distinct = assume_distinct;
         return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
     return false;

@@ -399,3 +399,27 @@ def test_full_size_properties():
     u = ctx.count(r, k, B.CANONICAL | B.UNSORTED)
     assert 2 * len(u) == n                                           # odd k: no self-reverse-complementary k-mers
     ctx.close()
+
+
+def test_direct_sorted_output_withdrawn(ctx, monkeypatch, capfd):
+    """Odd k: the both-strand set of a distinct canonical set holds no duplicates, so the sorting kernels write the
+    dense result directly (no compaction pass).  A thousand k-mers that differ only in their first five bases crowd
+    one bin of the in-bucket distribution sort: that bucket is left to the second-chance kernel, the direct output
+    is withdrawn and the pass redone in place -- the result must not change."""
+    import random
+    rnd = random.Random(11)
+    suffix = "".join(rnd.choice("ACGT") for _ in range(16))
+    reads = synth_reads(1200, read_len=100, genome_len=6000, sub_rate=0.01, seed=12)
+    reads += ["".join(rnd.choice("ACGT") for _ in range(30)) + suffix for _ in range(4000)]
+    monkeypatch.setenv("BBK_VERBOSE", "1")
+    for flags in (B.BOTH_STRANDS, B.BOTH_STRANDS | B.REFERENCE_ORDER | B.WITH_COUNTS):
+        exp, expc = O.kmercount(reads, 21, 16, 2, with_counts=True)
+        s = ctx.count(ctx.reads_from_ascii(reads), 21, flags)
+        if flags & B.WITH_COUNTS:
+            got, gotc = s.export(B.ORDER_REFERENCE_BUCKETS16, with_counts=True)
+            assert np.array_equal(gotc, expc)
+        else:
+            got = s.export(B.ORDER_REFERENCE_BUCKETS16)
+        assert np.array_equal(got, exp)
+    err = capfd.readouterr().err
+    assert "direct output withdrawn" in err
