@@ -51,7 +51,9 @@ static bool msd_two_stage(bbk_ctx *ctx, unsigned k, const bbk_reads *rd, const v
     const bool v = op1 != MSD_OP_NONE;
     const int op2 = !v ? MSD_OP_NONE : (with_mask ? MSD_OP_OR : MSD_OP_SUM);
     MsdOutput b;
-    if (!msd_sort_reduce(ctx, k, MSD_KEYS, op2, nullptr, a.keys.p, v ? a.vals.as<uint32_t>() : nullptr, a.n, false, b))
+    // stage A left distinct records: stage B only orders them (assume_distinct: the sorted result is written directly)
+    if (!msd_sort_reduce(ctx, k, MSD_KEYS, op2, nullptr, a.keys.p, v ? a.vals.as<uint32_t>() : nullptr, a.n, false, b, 0u,
+                         /*assume_distinct=*/true))
         return false;
     out_keys = std::move(b.keys);
     if (v) out_vals = std::move(b.vals);
