@@ -258,33 +258,31 @@ static void expand_both_strands(bbk_ctx *ctx, unsigned k, const DevBuf &ck, cons
         return;
     }
     BBK_REQUIRE(2 * D < (1ull << 32), BBK_ERR_ARG, "too many distinct k-mers for one device batch");
+    bool tag = want_ref && W == 1 && 2 * k + 4 <= 64 && msd_enabled();
+    if (msd_enabled()) {
+        // fused: the level-1 partition kernels generate key, reverse complement (and tag) from the canonical array
+        // themselves -- the expanded array is never written
+        MsdOutput m;
+        const bool ref_prefix = want_ref && !tag && W <= 2;
+        if (msd_sort_reduce(ctx, k, ref_prefix ? MSD_REF : MSD_KEYS, wc ? MSD_OP_SUM : MSD_OP_NONE, nullptr, ck.p,
+                            wc ? cv->as<uint32_t>() : nullptr, D, false, m, tag ? 4u : 0u,
+                            /*assume_distinct: odd k has no self-reverse-complementary k-mers*/ (k & 1) != 0,
+                            /*expand_k=*/k)) {
+            s.n = m.n;
+            s.keys = std::move(m.keys);
+            if (wc) s.counts = std::move(m.vals);
+            s.ref_order = tag || ref_prefix;
+            return;
+        }
+    }
+    // general path: materialise the expanded array, sort, unique
     DevBuf e(2 * D * rec), et(2 * D * rec), ec, ect;
     if (wc) {
         ec.alloc(2 * D * 4);
         ect.alloc(2 * D * 4);
     }
-    bool tag = want_ref && W == 1 && 2 * k + 4 <= 64 && msd_enabled();
-    for (;;) {
-        BBK_DISPATCH_W(W, launch_expand<W_>(ctx, ck.p, wc ? cv->as<uint32_t>() : nullptr, D, (int)k, e.p,
-                                            wc ? ec.as<uint32_t>() : nullptr, tag));
-        if (msd_enabled()) {
-            MsdOutput m;
-            // 16-byte keys have no spare bits in word 0 for the tag: the REF prefix (XXH3 bucket, then key bits)
-            // partitions them into the final_kmers order directly, at the price of the hash in every level
-            const bool ref_prefix = want_ref && !tag && W <= 2;  // 8-byte keys without room for the tag (k = 31, 32) too
-            if (msd_sort_reduce(ctx, k, ref_prefix ? MSD_REF : MSD_KEYS, wc ? MSD_OP_SUM : MSD_OP_NONE, nullptr, e.p,
-                                wc ? ec.as<uint32_t>() : nullptr, 2 * D, false, m, tag ? 4u : 0u,
-                                /*assume_distinct: odd k has no self-reverse-complementary k-mers*/ (k & 1) != 0)) {
-                s.n = m.n;
-                s.keys = std::move(m.keys);
-                if (wc) s.counts = std::move(m.vals);
-                s.ref_order = tag || ref_prefix;
-                return;
-            }
-        }
-        if (!tag) break;
-        tag = false;  // the tagged sort declined: expand again without tags and take the generic path
-    }
+    BBK_DISPATCH_W(W, launch_expand<W_>(ctx, ck.p, wc ? cv->as<uint32_t>() : nullptr, D, (int)k, e.p,
+                                        wc ? ec.as<uint32_t>() : nullptr, false));
     sort_records(ctx, W, e.p, et.p, wc ? ec.as<uint32_t>() : nullptr, wc ? ect.as<uint32_t>() : nullptr, 2 * D,
                  key_passes(k));
     const uint64_t D2 = unique_records(ctx, W, e.p, wc ? ec.as<uint32_t>() : nullptr, 2 * D, et.p,

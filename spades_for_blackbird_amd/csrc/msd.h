@@ -27,7 +27,10 @@ struct MsdOutput {
 // (tag, k-mer) and the tag is cleared in the output.
 bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_reads *rd, const void *d_keys,
                      const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out, unsigned tag_bits = 0,
-                     bool assume_distinct = false);
+                     bool assume_distinct = false, unsigned expand_k = 0);
+// expand_k = k (key array input): the array holds n CANONICAL k-mers and the records are generated on the fly -- 2n of
+// them: every key and its reverse complement, with the tag of tag_bits (the XXH3 bucket of 16) written by the
+// level-1 kernels themselves.
 // assume_distinct (key array, KEYS / REF prefix): the caller expects no duplicates, so the sorted result is written
 // directly at the offsets of the input (no compaction pass); verified on the fly, redone in place otherwise.
 

@@ -205,6 +205,11 @@ struct TileMap {
     uint32_t group;   // histogram kernels: consecutive tiles one workgroup walks
     const uint4 *desc;  // level 2: per tile (first record, records, bins of its segment, flat index of bin 0),
                         // precomputed so that a workgroup starts with one load instead of a binary search
+    // level 1 over a CANONICAL key array that is expanded on the fly: record 2c is key c, record 2c+1 its reverse
+    // complement (the both-strand set of spades-kmercount; M.n counts records); expand_tag: the XXH3 bucket of 16
+    // goes into bits 2k..2k+3 of either (final_kmers order by one ascending sort, see count.hip)
+    int expand_k;  // 0: the array holds the records themselves
+    int expand_tag;
 };
 
 // level 2: tile -> descriptor (one thread per tile)
@@ -392,8 +397,21 @@ typedef uint64_t KeyPair __attribute__((ext_vector_type(2), aligned(8)));  // 16
 // would be waited for before the next one is issued: one memory latency per record)
 template <int W, int ITEMS, int THREADS, bool HAS_VAL>
 __device__ __forceinline__ void tile_load(const Key<W> *__restrict__ in, const uint32_t *__restrict__ vin, uint64_t begin,
-                                          uint32_t count, int tid, Key<W> (&keys)[ITEMS], uint32_t (&vals)[ITEMS]) {
-    if constexpr (W == 1) {
+                                          uint32_t count, int tid, Key<W> (&keys)[ITEMS], uint32_t (&vals)[ITEMS],
+                                          int expand_k = 0, int expand_tag = 0) {
+    if (expand_k) {  // uniform: record r of the tile = canonical key r/2 (even r) or its reverse complement (odd r)
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t local = tile_local<W, THREADS>(i, tid);
+            const uint64_t rec = begin + (local < count ? local : count - 1u);  // clamped into the tile
+            const uint64_t at = rec >> 1;
+            Key<W> x = key_load<W>(&in[at]);
+            if (rec & 1) x = kmer_rc<W>(x, expand_k);
+            if (W == 1 && expand_tag) x.w[0] |= __umul64hi(xxh3_64<W>(x), 16ull) << (2 * expand_k);
+            keys[i] = x;
+            vals[i] = HAS_VAL ? vin[at] : 0u;
+        }
+    } else if constexpr (W == 1) {
         if (count == (uint32_t)(ITEMS * THREADS)) {  // full tile (uniform): pairs
             const uint64_t *base = reinterpret_cast<const uint64_t *>(in) + begin;
 #pragma unroll
@@ -471,7 +489,8 @@ __global__ __launch_bounds__(PartCfg<W>::THREADS) void k_part(const Key<W> *__re
             }
             Key<W> keys[kPartItems];
             uint32_t unused[kPartItems];
-            tile_load<W, kPartItems, kPartThreads, false>(in, nullptr, begin, count, tid, keys, unused);
+            tile_load<W, kPartItems, kPartThreads, false>(in, nullptr, begin, count, tid, keys, unused, M.expand_k,
+                                                          M.expand_tag);
 #pragma unroll
             for (int i = 0; i < kPartItems; ++i) {
                 const uint32_t local = tile_local<W, kPartThreads>(i, tid);
@@ -506,7 +525,7 @@ __global__ __launch_bounds__(PartCfg<W>::THREADS) void k_part(const Key<W> *__re
     Key<W> keys[kPartItems];
     uint32_t vals[kPartItems];
     uint32_t binrank[kPartItems];  // bin << 16 | rank (rank < 8192 fits 13 bits; bins < 1024)
-    tile_load<W, kPartItems, kPartThreads, HAS_VAL>(in, vin, begin, count, tid, keys, vals);
+    tile_load<W, kPartItems, kPartThreads, HAS_VAL>(in, vin, begin, count, tid, keys, vals, M.expand_k, M.expand_tag);
     // keep the records in registers: otherwise hipcc re-loads them from (restrict, read-only) memory for the LDS
     // reorder, which doubles the L2 traffic and, vmcnt being in-order, puts the reservation atomics issued in
     // between back on the critical path
@@ -1768,6 +1787,8 @@ struct MsdRunner {
     bool slots_ok = getenv("BBK_NO_SLOTS") == nullptr;  // histogram-free slot mode allowed (HASH prefix)
     bool never_decline = false;  // finish whatever overflows bucket by bucket on the LSD path instead of declining
     bool assume_distinct = false;  // caller's hint (key arrays, KEYS / REF prefix): duplicates are not expected
+    unsigned expand_k = 0;         // key-array input holds CANONICAL k-mers of this length: both strands are generated
+    bool expand_tag = false;       // ... with the XXH3 bucket tag above the k-mer (the runner's k is then k + 2)
 
     template <bool HAS_VAL, bool HIST>
     void launch_part(const char *fam, double bytes, uint32_t ntiles, const Key<W> *in, const uint32_t *vin, TileMap M,
@@ -1915,7 +1936,7 @@ struct MsdRunner {
 
         // ---- instance space (reads: k-mers for the sizes, chunks for the level-1 tiles)
         DevBuf coff, tile_read;
-        uint64_t N = n_in, n_chunks = 0;
+        uint64_t N = (expand_k && rd == nullptr) ? 2 * n_in : n_in, n_chunks = 0;
         if (from_reads) {
             BBK_REQUIRE(dmode == MSD_HASH, BBK_ERR_INTERNAL, "reads are partitioned by hash prefix only");
             DevBuf nk((rd->n + 1) * sizeof(uint64_t));
@@ -2001,7 +2022,7 @@ struct MsdRunner {
             Sh = S;
             Sh.tiles = tiles_h.as<RdTile>();
         }
-        TileMap M1{nullptr, nullptr, nullptr, 1, Ntot, 0, 1, nullptr};
+        TileMap M1{nullptr, nullptr, nullptr, 1, Ntot, 0, 1, nullptr, (int)expand_k, expand_tag ? 1 : 0};
 
         // ---- slot mode (HASH prefix + LDS hash dedup): no histogram passes.  The hash spreads the records evenly,
         // so every level-1 segment gets a fixed slot of the mean size + 1 % and every bucket a slot of the dedup
@@ -2135,7 +2156,7 @@ struct MsdRunner {
         BBK_HIP(hipMemcpyAsync(seg_size.p, h1.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
         PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), sel_bits, sel_val};
         const uint32_t ntiles2 = tstart[nb1];
-        TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), seg_size.as<uint32_t>(), nb1, N, ntiles2, 1, nullptr};
+        TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), seg_size.as<uint32_t>(), nb1, N, ntiles2, 1, nullptr, 0, 0};
         DevBuf desc2((size_t)ntiles2 * sizeof(uint4) + 16);
         if (ntiles2) {
             hipLaunchKernelGGL(k_tile_desc, dim3((ntiles2 + 255) / 256), dim3(256), 0, ctx->stream, M2, seg_nb2.as<uint32_t>(),
@@ -2319,6 +2340,7 @@ struct MsdRunner {
                                   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull};
                     MsdRunner<W> sorter = *this;
                     sorter.dmode = MSD_KEYS;  // picks the sorting kernels in bucket_dispatch
+                    sorter.expand_k = 0;
                     sorter.template bucket_dispatch<true>(1u, ek.as<Key<W>>(), ev.as<uint32_t>(), At,
                                                           (double)n_extra * (rec + (has_val ? 4 : 0)),
                                                           /*allow_hash=*/false);
@@ -2338,6 +2360,7 @@ struct MsdRunner {
                 exact.slots_ok = false;
                 exact.dmode = MSD_KEYS;
                 exact.never_decline = true;
+                exact.expand_k = 0;
                 // declined (e.g. one k-mer makes up most of it): so does this call, the caller takes the LSD path
                 if (!exact.run_all(nullptr, ek.p, has_val ? ev.as<uint32_t>() : nullptr, n_extra, false, extra)) return 0;
                 extra.bucket_off.release();
@@ -2526,16 +2549,19 @@ static void dump_phases() {
 
 bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_reads *rd, const void *d_keys,
                      const uint32_t *d_vals, uint64_t n, bool with_mask, MsdOutput &out, unsigned tag_bits,
-                     bool assume_distinct) {
+                     bool assume_distinct, unsigned expand_k) {
     const int W = (int)words_of(k);
     if (tag_bits) {
         // the tag sits right above the k-mer (bits [2k, 2k + tag_bits)): sort as a (k + tag_bits/2)-mer, clear the
         // tag on the way out
-        BBK_REQUIRE(W == 1 && rd == nullptr && dmode == MSD_KEYS && tag_bits % 2 == 0 && 2 * k + tag_bits <= 64,
+        BBK_REQUIRE(W == 1 && rd == nullptr && dmode == MSD_KEYS && tag_bits % 2 == 0 && 2 * k + tag_bits <= 64 &&
+                        (expand_k == 0 || expand_k == k),
                     BBK_ERR_INTERNAL, "tagged sort needs 8-byte keys with %u spare bits", tag_bits);
         MsdRunner<1> r{ctx, k + tag_bits / 2, dmode, op, d_vals != nullptr};
         r.strip_mask = (2 * k >= 64) ? ~0ull : ((1ull << (2 * k)) - 1ull);
         r.assume_distinct = assume_distinct;
+        r.expand_k = expand_k;
+        r.expand_tag = expand_k != 0;
         return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
 #ifdef BBK_PHASE_PROF
@@ -2546,21 +2572,25 @@ bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_read
     if (W == 1) {
         MsdRunner<1> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
         r.assume_distinct = assume_distinct;
+        r.expand_k = expand_k;
         return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
     if (W == 2) {
         MsdRunner<2> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
         r.assume_distinct = assume_distinct;
+        r.expand_k = expand_k;
         return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
     if (W == 3) {
         MsdRunner<3> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
         r.assume_distinct = assume_distinct;
+        r.expand_k = expand_k;
         return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
     if (W == 4) {
         MsdRunner<4> r{ctx, k, dmode, op, with_mask || d_vals != nullptr};
         r.assume_distinct = assume_distinct;
+        r.expand_k = expand_k;
         return r.run_all(rd, d_keys, d_vals, n, with_mask, out);
     }
     return false;
