@@ -102,6 +102,22 @@ void bbk_reads_free(bbk_reads *r);
                                   (projects/kmercount/main.cpp:214-219).  Exporting in that order is then a plain copy
                                   and bbk_kmerset_keys() is the result itself */
 int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, bbk_kmerset **out);
+/* Streaming count: the input never has to be resident as a whole.  Replaces the bounded-memory contract of
+ * KMerSortingSplitter -- per-thread cells of `-b` bytes (PrepareBuffers, common/utils/kmer_mph/kmer_splitter.hpp:73-109),
+ * one sorted + uniqued run per bucket every time the cells fill up (DumpBuffers, :120-167), and the loser-tree merge of
+ * the runs at the end (KMerDiskCounter::MergeKMers, kmer_index_builder.hpp:281-365).  Every pushed batch is
+ * deduplicated on the device and kept as a run of distinct canonical k-mers; runs are merge-uniqued into the
+ * accumulated set as they pile up; bbk_count_finish orders the set as `flags` ask (same flags and same result as one
+ * bbk_count over the concatenated batches).  Device memory is bounded by the batch and the DISTINCT set, host memory
+ * by the batch.  bbk_count_finish releases the counter (also on failure); bbk_count_abort drops it without a result. */
+typedef struct bbk_counter bbk_counter;
+int bbk_count_begin(bbk_ctx *ctx, unsigned k, unsigned flags, bbk_counter **out);
+int bbk_count_push_reads(bbk_counter *c, const bbk_reads *reads);
+/* ASCII batch (same arguments and LongestValid rule as bbk_reads_from_ascii) */
+int bbk_count_push_ascii(bbk_counter *c, const char *h_bases, const uint64_t *h_offsets, uint64_t n_reads);
+int bbk_count_finish(bbk_counter *c, bbk_kmerset **out);
+void bbk_count_abort(bbk_counter *c);
+uint64_t bbk_count_pushed_instances(const bbk_counter *c); /* k-mer positions seen so far */
 /* Device pointer to the records of the set (size * words u64) in the order it is stored in; valid until
  * bbk_kmerset_free.  *order receives BBK_ORDER_SORTED / BBK_ORDER_REFERENCE_BUCKETS16, or 0xFFFFFFFF for a
  * BBK_UNSORTED set. */
@@ -146,6 +162,13 @@ int bbk_kmerset_write_final_kmers(bbk_ctx *ctx, const bbk_kmerset *s, const char
 /* ---- extension index: replaces DeBruijnExtensionIndexBuilder::BuildExtensionIndexFromStream
  *      (common/utils/extension_index/kmer_extension_index_builder.hpp:62-106) -------------- */
 int bbk_extindex_build(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, bbk_extindex **out);
+/* Streaming build (same contract as bbk_count_begin / push / finish): (canonical k-mer, mask bits) records of every
+ * pushed batch are OR-reduced on the device, merged as they pile up, ordered once by bbk_extindex_finish. */
+typedef struct bbk_extbuilder bbk_extbuilder;
+int bbk_extindex_begin(bbk_ctx *ctx, unsigned k, bbk_extbuilder **out);
+int bbk_extindex_push_reads(bbk_extbuilder *b, const bbk_reads *reads);
+int bbk_extindex_finish(bbk_extbuilder *b, bbk_extindex **out);
+void bbk_extindex_abort(bbk_extbuilder *b);
 uint64_t bbk_extindex_size(const bbk_extindex *x);
 unsigned bbk_extindex_k(const bbk_extindex *x);
 /* sorted canonical k-mers (size*words u64) and their InOutMask bytes

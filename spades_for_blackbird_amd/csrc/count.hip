@@ -21,6 +21,7 @@
 #include "bbk_internal.h"
 #include "kmer_ops.h"
 #include "msd.h"
+#include "accum.h"
 
 namespace bbk {
 
@@ -28,37 +29,6 @@ namespace bbk {
 static bool msd_enabled() {
     const char *e = getenv("BBK_DISABLE_MSD");
     return !(e && e[0] == '1');
-}
-
-// Fast path for "distinct + reduce, ascending": hash-partitioned sort-reduce of the raw stream, then
-// a second (small) sort-reduce of the distinct records partitioned on the key bits themselves.
-// Returns false if the MSD path declined; nothing has been written to the outputs then.
-static bool msd_two_stage(bbk_ctx *ctx, unsigned k, const bbk_reads *rd, const void *d_keys, const uint32_t *d_vals,
-                          uint64_t n, bool with_mask, bool want_vals, DevBuf &out_keys, DevBuf &out_vals,
-                          uint64_t &n_distinct, uint64_t &n_instances) {
-    if (!msd_enabled()) return false;
-    const bool in_vals = with_mask || d_vals != nullptr;
-    const int op1 = with_mask ? MSD_OP_OR : (in_vals ? MSD_OP_SUM : (want_vals ? MSD_OP_COUNT : MSD_OP_NONE));
-    MsdOutput a;
-    if (!msd_sort_reduce(ctx, k, MSD_HASH, op1, rd, d_keys, d_vals, n, with_mask, a)) return false;
-    n_instances = a.instances;
-    if (a.n == 0) {
-        out_keys.alloc(16);
-        out_vals.alloc(16);
-        n_distinct = 0;
-        return true;
-    }
-    const bool v = op1 != MSD_OP_NONE;
-    const int op2 = !v ? MSD_OP_NONE : (with_mask ? MSD_OP_OR : MSD_OP_SUM);
-    MsdOutput b;
-    // stage A left distinct records: stage B only orders them (assume_distinct: the sorted result is written directly)
-    if (!msd_sort_reduce(ctx, k, MSD_KEYS, op2, nullptr, a.keys.p, v ? a.vals.as<uint32_t>() : nullptr, a.n, false, b, 0u,
-                         /*assume_distinct=*/true))
-        return false;
-    out_keys = std::move(b.keys);
-    if (v) out_vals = std::move(b.vals);
-    n_distinct = b.n;
-    return true;
 }
 
 __global__ void k_kmers_per_read(const uint32_t *__restrict__ len, uint64_t n, uint32_t k,
@@ -171,30 +141,28 @@ static void launch_expand(bbk_ctx *ctx, const void *in, const uint32_t *cin, uin
         default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %d", (int)(W)); \
     }
 
-uint64_t drop_zero_vals(bbk_ctx *ctx, int W, const void *keys, const uint32_t *vals, uint64_t n, void *out_keys,
-                        uint32_t *out_vals);
+uint64_t drop_zero_vals(bbk_ctx *ctx, int W, const void *keys, const uint32_t *vals, uint64_t n, DevBuf &out_keys,
+                        DevBuf &out_vals);
 
-// Extract one record per k-mer position, sort, reduce.  Result: distinct canonical keys
-// (ascending) + payload (COUNT: multiplicity; OR: InOutMask).  Shared with extindex.hip.
-void count_canonical(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_mask, bool want_vals, DevBuf &out_keys,
-                     DevBuf &out_vals, uint64_t &n_distinct, uint64_t &n_instances) {
+// ---- stage A: distinct canonical records (+ reduced payload) of one batch of reads, in ANY order ------------
+// payload: with_mask -> OR of the InOutMask bits of every occurrence; want_vals -> multiplicity.
+// MSD path (hash-partitioned dedup in LDS, hash-range passes above one device pass); LSD fallback = extract, sort,
+// unique (its output happens to be ascending).
+void dedup_reads(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_mask, bool want_vals, DevBuf &out_keys,
+                 DevBuf &out_vals, uint64_t &n_distinct, uint64_t &n_instances) {
     const int W = (int)words_of(k);
     n_distinct = 0;
     n_instances = 0;
-    if (msd_two_stage(ctx, k, rd, nullptr, nullptr, 0, with_mask, want_vals, out_keys, out_vals, n_distinct,
-                      n_instances)) {
-        if (with_mask && n_distinct) {
-            // k-mers that never received a bit (reads of length exactly k) are not part of the index
-            DevBuf fk(n_distinct * (size_t)W * 8), fv(n_distinct * 4);
-            const uint64_t kept = drop_zero_vals(ctx, W, out_keys.p, out_vals.as<uint32_t>(), n_distinct, fk.p,
-                                                 fv.as<uint32_t>());
-            if (kept != n_distinct) {
-                out_keys = std::move(fk);
-                out_vals = std::move(fv);
-                n_distinct = kept;
-            }
+    if (msd_enabled()) {
+        const int op1 = with_mask ? MSD_OP_OR : (want_vals ? MSD_OP_COUNT : MSD_OP_NONE);
+        MsdOutput a;
+        if (msd_sort_reduce(ctx, k, MSD_HASH, op1, rd, nullptr, nullptr, 0, with_mask, a)) {
+            n_instances = a.instances;
+            n_distinct = a.n;
+            out_keys = std::move(a.keys);
+            if (op1 != MSD_OP_NONE) out_vals = std::move(a.vals);
+            return;
         }
-        return;
     }
     DevBuf koff((rd->n + 1) * sizeof(uint64_t));
     if (rd->n) {
@@ -210,7 +178,8 @@ void count_canonical(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_ma
         return;
     }
     BBK_REQUIRE(N < (1ull << 32), BBK_ERR_ARG,
-                "batch holds %llu k-mer instances; a single device batch is limited to 2^32-1 (split the reads)",
+                "batch holds %llu k-mer instances; the LSD path is limited to 2^32-1 per batch (push the reads in "
+                "smaller batches)",
                 (unsigned long long)N);
     const size_t rec = (size_t)W * 8;
     DevBuf keys(N * rec), tmp(N * rec), vals, vtmp;
@@ -229,17 +198,154 @@ void count_canonical(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_ma
         rv = vtmp.as<uint32_t>();
     }
     const uint64_t D = unique_records(ctx, W, keys.p, with_mask ? vals.as<uint32_t>() : nullptr, N, tmp.p, rv,
-                                      with_mask ? REDUCE_OR : REDUCE_COUNT, /*drop_zero=*/with_mask);
+                                      with_mask ? REDUCE_OR : REDUCE_COUNT, /*drop_zero=*/false);
     keys.release();
     vals.release();
-    out_keys.alloc(D * rec);
+    out_keys.alloc(D * rec + 16);
     BBK_HIP(hipMemcpyAsync(out_keys.p, tmp.p, D * rec, hipMemcpyDeviceToDevice, ctx->stream));
     if (rv) {
-        out_vals.alloc(D * 4);
+        out_vals.alloc(D * 4 + 16);
         BBK_HIP(hipMemcpyAsync(out_vals.p, rv, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
     BBK_HIP(hipStreamSynchronize(ctx->stream));
     n_distinct = D;
+}
+
+// LSD sort + unique of a record array (the general path behind every MSD call that declines)
+static uint64_t lsd_sort_unique(bbk_ctx *ctx, unsigned k, const void *d_keys, const uint32_t *d_vals, uint64_t n,
+                                ReduceOp rop, DevBuf &out_keys, DevBuf &out_vals) {
+    const int W = (int)words_of(k);
+    const size_t rec = (size_t)W * 8;
+    BBK_REQUIRE(n < (1ull << 32), BBK_ERR_ARG, "%llu records exceed the LSD path's 2^32-1", (unsigned long long)n);
+    DevBuf a(n * rec), b(n * rec), ca, cb;
+    BBK_HIP(hipMemcpyAsync(a.p, d_keys, n * rec, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_vals) {
+        ca.alloc(n * 4);
+        cb.alloc(n * 4);
+        BBK_HIP(hipMemcpyAsync(ca.p, d_vals, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    sort_records(ctx, W, a.p, b.p, d_vals ? ca.as<uint32_t>() : nullptr, d_vals ? cb.as<uint32_t>() : nullptr, n,
+                 key_passes(k));
+    const uint64_t D = unique_records(ctx, W, a.p, d_vals ? ca.as<uint32_t>() : nullptr, n, b.p,
+                                      d_vals ? cb.as<uint32_t>() : nullptr, rop, false);
+    out_keys.alloc(D * rec + 16);
+    BBK_HIP(hipMemcpyAsync(out_keys.p, b.p, D * rec, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_vals) {
+        out_vals.alloc(D * 4 + 16);
+        BBK_HIP(hipMemcpyAsync(out_vals.p, cb.p, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    BBK_HIP(hipStreamSynchronize(ctx->stream));
+    return D;
+}
+
+// Distinct records of a record array (payloads summed / OR-ed), in ANY order: the merge step of the streaming
+// count (MergeKMers analogue, kmer_index_builder.hpp:281-365) and of the multi-GPU exchange.
+static uint64_t dedup_keys(bbk_ctx *ctx, unsigned k, const void *d_keys, const uint32_t *d_vals, uint64_t n, int op,
+                           DevBuf &out_keys, DevBuf &out_vals) {
+    if (n == 0) {
+        out_keys.alloc(16);
+        if (d_vals) out_vals.alloc(16);
+        return 0;
+    }
+    if (msd_enabled()) {
+        MsdOutput m;
+        if (msd_sort_reduce(ctx, k, MSD_HASH, op, nullptr, d_keys, d_vals, n, false, m)) {
+            out_keys = std::move(m.keys);
+            if (op != MSD_OP_NONE) out_vals = std::move(m.vals);
+            return m.n;
+        }
+    }
+    return lsd_sort_unique(ctx, k, d_keys, d_vals, n, op == MSD_OP_OR ? REDUCE_OR : REDUCE_SUM, out_keys, out_vals);
+}
+
+// ---- stage B: a distinct set -> ascending (word 0 most significant, adt/array_vector.hpp:114-123) ---------------
+static uint64_t sort_distinct(bbk_ctx *ctx, unsigned k, const void *d_keys, const uint32_t *d_vals, uint64_t n, int op,
+                              DevBuf &out_keys, DevBuf &out_vals) {
+    if (n == 0) {
+        out_keys.alloc(16);
+        if (d_vals) out_vals.alloc(16);
+        return 0;
+    }
+    if (msd_enabled()) {
+        MsdOutput b;
+        // the input is distinct: stage B only orders it (assume_distinct: the sorted result is written directly)
+        if (msd_sort_reduce(ctx, k, MSD_KEYS, d_vals ? op : MSD_OP_NONE, nullptr, d_keys, d_vals, n, false, b, 0u,
+                            /*assume_distinct=*/true)) {
+            out_keys = std::move(b.keys);
+            if (d_vals) out_vals = std::move(b.vals);
+            return b.n;
+        }
+    }
+    return lsd_sort_unique(ctx, k, d_keys, d_vals, n, op == MSD_OP_OR ? REDUCE_OR : REDUCE_SUM, out_keys, out_vals);
+}
+
+// ---- accumulator of the streaming entry points -----------------------------------------------------------------
+// What the reference gets from bounded per-thread cells, repeated DumpBuffers rounds (one sorted + uniqued run per
+// bucket and round, kmer_splitter.hpp:73-167) and the final loser-tree run merge (MergeKMers,
+// kmer_index_builder.hpp:281-365): the input never has to be resident as a whole.  Here every pushed batch is
+// deduplicated on its own (stage A) and kept as a "run" of distinct canonical records; runs are merge-uniqued into
+// the accumulated set whenever they outweigh half of it (so the total merge work stays linear in the input), and
+// finish() orders the set once.
+bool Accum::has_vals() const { return with_mask || want_vals; }
+int Accum::merge_op() const { return with_mask ? MSD_OP_OR : (want_vals ? MSD_OP_SUM : MSD_OP_NONE); }
+
+void Accum::push(const bbk_reads *rd) {
+    Run r;
+    uint64_t inst = 0;
+    dedup_reads(ctx, rd, k, with_mask, want_vals, r.keys, r.vals, r.n, inst);
+    instances += inst;
+    ++batches;
+    if (r.n == 0) return;
+    runs_n += r.n;
+    runs.push_back(std::move(r));
+    static const char *e = getenv("BBK_MERGE_MIN");  // tests force a merge after every push
+    const uint64_t floor_n = e ? strtoull(e, nullptr, 10) : (32ull << 20);
+    if ((runs.size() > 1 || n) && runs_n >= n / 2 + floor_n) merge();
+}
+
+// accumulated set + runs -> accumulated set
+void Accum::merge() {
+    if (runs.empty()) return;
+    if (n == 0 && runs.size() == 1) {  // first batch: adopt
+        keys = std::move(runs[0].keys);
+        vals = std::move(runs[0].vals);
+        n = runs[0].n;
+        runs.clear();
+        runs_n = 0;
+        return;
+    }
+    const size_t rec = (size_t)words_of(k) * 8;
+    const uint64_t total = n + runs_n;
+    DevBuf ck(total * rec + 16), cv;
+    if (has_vals()) cv.alloc(total * 4 + 16);
+    uint64_t o = 0;
+    auto put = [&](DevBuf &kb, DevBuf &vb, uint64_t cnt) {
+        if (!cnt) return;
+        BBK_HIP(hipMemcpyAsync(ck.as<char>() + o * rec, kb.p, cnt * rec, hipMemcpyDeviceToDevice, ctx->stream));
+        if (has_vals())
+            BBK_HIP(hipMemcpyAsync(cv.as<uint32_t>() + o, vb.p, cnt * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        o += cnt;
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        kb.release();
+        vb.release();
+    };
+    put(keys, vals, n);
+    for (Run &r : runs) put(r.keys, r.vals, r.n);
+    runs.clear();
+    runs_n = 0;
+    n = dedup_keys(ctx, k, ck.p, has_vals() ? cv.as<uint32_t>() : nullptr, total, merge_op(), keys, vals);
+    ++merges;
+}
+
+// the accumulated set in ascending order (payloads alongside); the accumulator is left empty
+uint64_t Accum::finish_sorted(DevBuf &out_keys, DevBuf &out_vals) {
+    merge();
+    const uint64_t D = sort_distinct(ctx, k, keys.p, has_vals() ? vals.as<uint32_t>() : nullptr, n, merge_op(), out_keys,
+                                     out_vals);
+    keys.release();
+    vals.release();
+    n = 0;
+    return D;
 }
 
 // canon U rc(canon): expand, sort, unique.  A k-mer equal to its own RC (even k) appears twice
@@ -257,7 +363,8 @@ static void expand_both_strands(bbk_ctx *ctx, unsigned k, const DevBuf &ck, cons
         if (wc) s.counts.alloc(16);
         return;
     }
-    BBK_REQUIRE(2 * D < (1ull << 32), BBK_ERR_ARG, "too many distinct k-mers for one device batch");
+    // (sets above one device pass -- 2^32 records and far less for wide keys -- are sorted in key-range passes inside
+    // msd_sort_reduce; only the LSD fallback below keeps the 32-bit limit)
     bool tag = want_ref && W == 1 && 2 * k + 4 <= 64 && msd_enabled();
     if (msd_enabled()) {
         // fused: the level-1 partition kernels generate key, reverse complement (and tag) from the canonical array
@@ -276,6 +383,7 @@ static void expand_both_strands(bbk_ctx *ctx, unsigned k, const DevBuf &ck, cons
         }
     }
     // general path: materialise the expanded array, sort, unique
+    BBK_REQUIRE(2 * D < (1ull << 32), BBK_ERR_ARG, "too many distinct k-mers for the LSD path (%llu)", (unsigned long long)D);
     DevBuf e(2 * D * rec), et(2 * D * rec), ec, ect;
     if (wc) {
         ec.alloc(2 * D * 4);
@@ -304,80 +412,130 @@ static void check_k(unsigned k) {
     BBK_REQUIRE(k >= 1 && k < BBK_MAX_K, BBK_ERR_ARG, "k-mer size %u out of range [1,%d)", k, BBK_MAX_K);
 }
 
+// finish of a count: the accumulated distinct canonical set -> the bbk_kmerset the flags ask for
+static bbk_kmerset *finish_count(Accum &acc, unsigned flags) {
+    bbk_ctx *ctx = acc.ctx;
+    const unsigned k = acc.k;
+    const bool both = (flags & BBK_BOTH_STRANDS) != 0;
+    const bool wc = (flags & BBK_WITH_COUNTS) != 0;
+    const bool want_ref = (flags & BBK_REFERENCE_ORDER) != 0;
+    auto s = std::make_unique<bbk_kmerset>();
+    s->k = k;
+    s->W = words_of(k);
+    s->flags = flags;
+    s->has_counts = wc;
+    s->instances = both ? 2 * acc.instances : acc.instances;
+    acc.merge();
+    if (both) {
+        expand_both_strands(ctx, k, acc.keys, wc ? &acc.vals : nullptr, acc.n, *s, want_ref);
+        acc.keys.release();
+        acc.vals.release();
+    } else if (flags & BBK_UNSORTED) {
+        s->n = acc.n;
+        s->sorted = false;
+        s->keys = std::move(acc.keys);
+        if (wc) s->counts = std::move(acc.vals);
+        if (!s->keys.p) s->keys.alloc(16);
+    } else {
+        s->n = acc.finish_sorted(s->keys, s->counts);
+    }
+    acc.n = 0;
+    if (want_ref && !s->ref_order && s->sorted) {  // an ascending set -> the final_kmers order: one stable pass on the
+        if (s->n) {                                // XXH3 bucket (key widths without room for the tag / REF prefix)
+            const PassDesc pd{1, 0, 0, 8, 16};
+            DevBuf nk(s->n * (size_t)s->W * 8), nc;
+            if (wc) nc.alloc(s->n * 4);
+            partition_records(ctx, (int)s->W, s->keys.p, nk.p, wc ? s->counts.as<uint32_t>() : nullptr,
+                              wc ? nc.as<uint32_t>() : nullptr, s->n, pd);
+            s->keys = std::move(nk);
+            if (wc) s->counts = std::move(nc);
+        }
+        s->ref_order = true;
+    }
+    return s.release();
+}
+
+static void check_count_flags(unsigned flags) {
+    const bool both = (flags & BBK_BOTH_STRANDS) != 0, canon = (flags & BBK_CANONICAL) != 0;
+    BBK_REQUIRE(both != canon, BBK_ERR_ARG, "bbk_count: pass exactly one of BBK_BOTH_STRANDS / BBK_CANONICAL");
+    BBK_REQUIRE(!((flags & BBK_REFERENCE_ORDER) && (flags & BBK_UNSORTED)), BBK_ERR_ARG,
+                "bbk_count: BBK_REFERENCE_ORDER and BBK_UNSORTED exclude each other");
+}
+
 }  // namespace bbk
 
 using namespace bbk;
 
+struct bbk_counter {
+    bbk::Accum acc;
+    unsigned flags = 0;
+};
+
 extern "C" {
+
+int bbk_count_begin(bbk_ctx *ctx, unsigned k, unsigned flags, bbk_counter **out) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && out, BBK_ERR_ARG, "bbk_count_begin: NULL argument");
+        check_k(k);
+        check_count_flags(flags);
+        auto c = std::make_unique<bbk_counter>();
+        c->acc.ctx = ctx;
+        c->acc.k = k;
+        c->acc.want_vals = (flags & BBK_WITH_COUNTS) != 0;
+        c->flags = flags;
+        *out = c.release();
+    });
+}
+
+int bbk_count_push_reads(bbk_counter *c, const bbk_reads *reads) {
+    return guarded([&] {
+        BBK_REQUIRE(c && reads, BBK_ERR_ARG, "bbk_count_push_reads: NULL argument");
+        BBK_HIP(hipSetDevice(c->acc.ctx->device));
+        c->acc.push(reads);
+    });
+}
+
+int bbk_count_push_ascii(bbk_counter *c, const char *h_bases, const uint64_t *h_offsets, uint64_t n_reads) {
+    if (!c) {
+        set_error("bbk_count_push_ascii: NULL argument");
+        return BBK_ERR_ARG;
+    }
+    bbk_reads *r = nullptr;
+    const int rc = bbk_reads_from_ascii(c->acc.ctx, h_bases, h_offsets, n_reads, &r);
+    if (rc != BBK_OK) return rc;
+    const int rc2 = bbk_count_push_reads(c, r);
+    bbk_reads_free(r);
+    return rc2;
+}
+
+int bbk_count_finish(bbk_counter *c, bbk_kmerset **out) {
+    const int rc = guarded([&] {
+        BBK_REQUIRE(c && out, BBK_ERR_ARG, "bbk_count_finish: NULL argument");
+        BBK_HIP(hipSetDevice(c->acc.ctx->device));
+        *out = finish_count(c->acc, c->flags);
+    });
+    delete c;  // finished or failed: the counter is gone either way
+    return rc;
+}
+
+void bbk_count_abort(bbk_counter *c) { delete c; }
+
+uint64_t bbk_count_pushed_instances(const bbk_counter *c) { return c ? c->acc.instances : 0; }
 
 int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, bbk_kmerset **out) {
     return guarded([&] {
         BBK_REQUIRE(ctx && reads && out, BBK_ERR_ARG, "bbk_count: NULL argument");
         check_k(k);
-        const bool both = (flags & BBK_BOTH_STRANDS) != 0, canon = (flags & BBK_CANONICAL) != 0;
-        BBK_REQUIRE(both != canon, BBK_ERR_ARG, "bbk_count: pass exactly one of BBK_BOTH_STRANDS / BBK_CANONICAL");
-        const bool wc = (flags & BBK_WITH_COUNTS) != 0;
-        const bool want_ref = (flags & BBK_REFERENCE_ORDER) != 0;
-        BBK_REQUIRE(!(want_ref && (flags & BBK_UNSORTED)), BBK_ERR_ARG,
-                    "bbk_count: BBK_REFERENCE_ORDER and BBK_UNSORTED exclude each other");
+        check_count_flags(flags);
         BBK_HIP(hipSetDevice(ctx->device));
-        auto s = std::make_unique<bbk_kmerset>();
-        s->k = k;
-        s->W = words_of(k);
-        s->flags = flags;
-        s->has_counts = wc;
-        DevBuf ck, cv;
-        uint64_t D = 0, N = 0;
-        // an ascending set -> the final_kmers order: one stable pass on the XXH3 bucket
-        auto to_ref_order = [&](bbk_kmerset &ks) {
-            if (!want_ref || ks.ref_order) return;
-            if (ks.n) {
-                const PassDesc pd{1, 0, 0, 8, 16};
-                DevBuf nk(ks.n * (size_t)ks.W * 8), nc;
-                if (wc) nc.alloc(ks.n * 4);
-                partition_records(ctx, (int)ks.W, ks.keys.p, nk.p, wc ? ks.counts.as<uint32_t>() : nullptr,
-                                  wc ? nc.as<uint32_t>() : nullptr, ks.n, pd);
-                ks.keys = std::move(nk);
-                if (wc) ks.counts = std::move(nc);
-            }
-            ks.ref_order = true;
-        };
-        if (both && msd_enabled()) {
-            // fast path: hash-partitioned dedup of the canonical stream, then expand and sort once
-            MsdOutput a;
-            if (msd_sort_reduce(ctx, k, MSD_HASH, wc ? MSD_OP_COUNT : MSD_OP_NONE, reads, nullptr, nullptr, 0, false,
-                                a)) {
-                s->instances = 2 * a.instances;
-                expand_both_strands(ctx, k, a.keys, wc ? &a.vals : nullptr, a.n, *s, want_ref);
-                to_ref_order(*s);
-                *out = s.release();
-                return;
-            }
-        }
-        if (canon && (flags & BBK_UNSORTED) && msd_enabled()) {
-            MsdOutput a;
-            if (msd_sort_reduce(ctx, k, MSD_HASH, wc ? MSD_OP_COUNT : MSD_OP_NONE, reads, nullptr, nullptr, 0, false,
-                                a)) {
-                s->instances = a.instances;
-                s->n = a.n;
-                s->sorted = false;
-                s->keys = std::move(a.keys);
-                if (wc) s->counts = std::move(a.vals);
-                *out = s.release();
-                return;
-            }
-        }
-        count_canonical(ctx, reads, k, /*with_mask=*/false, wc, ck, cv, D, N);
-        s->instances = both ? 2 * N : N;
-        if (canon) {
-            s->n = D;
-            s->keys = std::move(ck);
-            if (wc) s->counts = std::move(cv);
-        } else {
-            expand_both_strands(ctx, k, ck, wc ? &cv : nullptr, D, *s, want_ref);
-        }
-        to_ref_order(*s);
-        *out = s.release();
+        // one batch through the streaming accumulator: hash-partitioned dedup of the canonical stream (stage A),
+        // then expand + sort once (stage B)
+        Accum acc;
+        acc.ctx = ctx;
+        acc.k = k;
+        acc.want_vals = (flags & BBK_WITH_COUNTS) != 0;
+        acc.push(reads);
+        *out = finish_count(acc, flags);
     });
 }
 

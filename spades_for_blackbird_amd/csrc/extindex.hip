@@ -16,13 +16,11 @@
 #include <algorithm>
 #include <memory>
 
+#include "accum.h"
 #include "bbk_internal.h"
 #include "kmer_ops.h"
 
 namespace bbk {
-
-void count_canonical(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_mask, bool want_vals, DevBuf &out_keys,
-                     DevBuf &out_vals, uint64_t &n_distinct, uint64_t &n_instances);
 
 __global__ void k_u32_to_u8(const uint32_t *__restrict__ in, uint64_t n, uint8_t *__restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -62,36 +60,109 @@ unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsi
 }
 
 void build_prefix_table(bbk_ctx *ctx, bbk_extindex *x) {
+    // table entries are 32-bit record indices: an index of 2^32 or more k-mers (BASELINE configs[3] gathered on one
+    // device) carries no lookup table and the graph stage refuses it (unitigs.hip); keys and masks are complete
+    if (x->n >= (1ull << 32)) {
+        x->prefix.release();
+        x->prefix_bits = 0;
+        return;
+    }
     x->prefix_bits = build_prefix_index(ctx, x->keys.as<uint64_t>(), x->W, x->k, x->n, x->prefix);
+}
+
+// the accumulated (canonical k-mer, OR of mask bits) records -> the index: ascending keys, one InOutMask byte each
+static bbk_extindex *finish_extindex(Accum &acc) {
+    bbk_ctx *ctx = acc.ctx;
+    auto x = std::make_unique<bbk_extindex>();
+    x->k = acc.k;
+    x->W = words_of(acc.k);
+    x->instances = acc.instances;
+    DevBuf m32;
+    x->n = acc.finish_sorted(x->keys, m32);
+    if (x->n) {
+        // k-mers that never received a bit (reads of length exactly k) are not part of the index
+        DevBuf fk, fv;
+        const uint64_t kept = drop_zero_vals(ctx, (int)x->W, x->keys.p, m32.as<uint32_t>(), x->n, fk, fv);
+        if (kept != x->n) {
+            x->keys = std::move(fk);
+            m32 = std::move(fv);
+            x->n = kept;
+        }
+    }
+    if (!x->keys.p) x->keys.alloc(16);
+    x->masks.alloc(x->n + 16);
+    if (x->n) {
+        const uint64_t nblk = (x->n + 255) / 256;
+        BBK_REQUIRE(nblk < (1ull << 31), BBK_ERR_ARG, "extension index of %llu k-mers exceeds the launch grid",
+                    (unsigned long long)x->n);
+        hipLaunchKernelGGL(k_u32_to_u8, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, m32.as<uint32_t>(), x->n,
+                           x->masks.as<uint8_t>());
+        check_launch("k_u32_to_u8");
+    }
+    build_prefix_table(ctx, x.get());
+    return x.release();
+}
+
+static void check_ext_k(unsigned k) {
+    // the index is built from (k+1)-mers, so k+1 must be a legal k-mer size too
+    BBK_REQUIRE(k >= 1 && k + 1 < BBK_MAX_K, BBK_ERR_ARG, "k-mer size %u out of range [1,%d)", k, BBK_MAX_K - 1);
 }
 
 }  // namespace bbk
 
 using namespace bbk;
 
+struct bbk_extbuilder {
+    bbk::Accum acc;
+};
+
 extern "C" {
 
 int bbk_extindex_build(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, bbk_extindex **out) {
     return guarded([&] {
         BBK_REQUIRE(ctx && reads && out, BBK_ERR_ARG, "bbk_extindex_build: NULL argument");
-        // the index is built from (k+1)-mers, so k+1 must be a legal k-mer size too
-        BBK_REQUIRE(k >= 1 && k + 1 < BBK_MAX_K, BBK_ERR_ARG, "k-mer size %u out of range [1,%d)", k, BBK_MAX_K - 1);
+        check_ext_k(k);
         BBK_HIP(hipSetDevice(ctx->device));
-        auto x = std::make_unique<bbk_extindex>();
-        x->k = k;
-        x->W = words_of(k);
-        DevBuf m32;
-        count_canonical(ctx, reads, k, /*with_mask=*/true, true, x->keys, m32, x->n, x->instances);
-        x->masks.alloc(x->n + 16);
-        if (x->n) {
-            hipLaunchKernelGGL(k_u32_to_u8, dim3((unsigned)((x->n + 255) / 256)), dim3(256), 0, ctx->stream,
-                               m32.as<uint32_t>(), x->n, x->masks.as<uint8_t>());
-            check_launch("k_u32_to_u8");
-        }
-        build_prefix_table(ctx, x.get());
-        *out = x.release();
+        Accum acc;
+        acc.ctx = ctx;
+        acc.k = k;
+        acc.with_mask = true;
+        acc.push(reads);
+        *out = finish_extindex(acc);
     });
 }
+
+int bbk_extindex_begin(bbk_ctx *ctx, unsigned k, bbk_extbuilder **out) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && out, BBK_ERR_ARG, "bbk_extindex_begin: NULL argument");
+        check_ext_k(k);
+        auto b = std::make_unique<bbk_extbuilder>();
+        b->acc.ctx = ctx;
+        b->acc.k = k;
+        b->acc.with_mask = true;
+        *out = b.release();
+    });
+}
+
+int bbk_extindex_push_reads(bbk_extbuilder *b, const bbk_reads *reads) {
+    return guarded([&] {
+        BBK_REQUIRE(b && reads, BBK_ERR_ARG, "bbk_extindex_push_reads: NULL argument");
+        BBK_HIP(hipSetDevice(b->acc.ctx->device));
+        b->acc.push(reads);
+    });
+}
+
+int bbk_extindex_finish(bbk_extbuilder *b, bbk_extindex **out) {
+    const int rc = guarded([&] {
+        BBK_REQUIRE(b && out, BBK_ERR_ARG, "bbk_extindex_finish: NULL argument");
+        BBK_HIP(hipSetDevice(b->acc.ctx->device));
+        *out = finish_extindex(b->acc);
+    });
+    delete b;
+    return rc;
+}
+
+void bbk_extindex_abort(bbk_extbuilder *b) { delete b; }
 
 uint64_t bbk_extindex_size(const bbk_extindex *x) { return x ? x->n : 0; }
 unsigned bbk_extindex_k(const bbk_extindex *x) { return x ? x->k : 0; }

@@ -93,10 +93,13 @@ struct PartLevel {
     // skewed prefix distribution still gives buckets of the target size) and flat bin base
     const uint32_t *seg_nb2;
     const uint32_t *seg_bin_start;
-    // hash-range pass (inputs above one device batch): only records whose prefix starts with sel_val
-    // (sel_bits bits) take part; the remaining prefix bits drive the bins
-    int sel_bits;
-    uint32_t sel_val;
+    // range pass (inputs above one device batch): only records whose prefix lies in [sel_lo, sel_lo + sel_span)
+    // take part (sel_span == 0: all of them); the prefix inside the range, (p - sel_lo) << sel_shl, drives the bins.
+    // HASH prefix: 2^b equal hash ranges; KEYS / REF prefix: ranges of the key space sized from a histogram, so the
+    // concatenated passes are in prefix order.
+    uint32_t sel_lo;
+    uint32_t sel_span;
+    int sel_shl;
     // slot mode (histogram-free HASH path): bin g of this level owns the fixed range [g*slot_cap, (g+1)*slot_cap) of
     // the output and `cursor[g]` starts at g*slot_cap; records that do not fit are appended to the spill list
     uint32_t slot_cap;     // 0: dense layout from an exact histogram
@@ -109,9 +112,10 @@ struct PartLevel {
 
 // applies the range selection: false = the record belongs to another pass; p loses the selection bits
 __device__ inline bool select_prefix(uint32_t &p, const PartLevel &L) {
-    if (L.sel_bits == 0) return true;
-    if ((p >> (32 - L.sel_bits)) != L.sel_val) return false;
-    p <<= L.sel_bits;
+    if (L.sel_span == 0) return true;
+    const uint32_t d = p - L.sel_lo;
+    if (d >= L.sel_span) return false;
+    p = d << L.sel_shl;
     return true;
 }
 
@@ -1918,16 +1922,33 @@ struct MsdRunner {
 
     // returns false if the caller should use the LSD path instead (too much overflow)
     // records two partition levels can take in one pass (bins <= 512 x ~768 of 0.7 CAP records)
-    uint64_t pass_limit() const {
+    // mean bucket fill the bin plan aims at.  Key arrays deduplicated through the LDS hash table (merge of received
+    // shards / pushed batches: multiplicity 1..few) are nearly all distinct: keep the table's load around 0.5 there
+    double plan_fill(bool from_reads) const { return (!from_reads && use_hash_dedup()) ? 0.52 : kBucketFill; }
+    uint64_t pass_limit(bool from_reads) const {
         static const char *e = getenv("BBK_PASS_LIMIT");  // tests force range passes on small inputs
         if (e) return strtoull(e, nullptr, 10);
-        return (uint64_t)(0.70 * 512 * 0.75 * kMaxBins * bucket_cap() * 0.98);
+        return (uint64_t)(plan_fill(from_reads) * 512 * 0.75 * kMaxBins * bucket_cap() * 0.98);
     }
 
-    // Returns 1 = done, 0 = declined (caller uses the LSD path), 2 = the reads hold more records than one
-    // pass takes: *need_sel_bits says into how many hash ranges (2^bits) the caller must split (HASH mode).
+    // One range of a range pass: prefixes in [lo, lo + span) (span == 0: everything), est = planning estimate of
+    // the records it holds (exact for KEYS / REF ranges, which come from a histogram).
+    struct Sel {
+        uint32_t lo = 0, span = 0;
+        int shl = 0;
+        uint64_t est = 0;
+    };
+    // Where the dense result of an exact-mode pass goes when the caller has already allocated it (range passes
+    // write one after the other into the final array: no concatenation copy of a 100 GB result).
+    struct Dst {
+        void *keys = nullptr;
+        uint32_t *vals = nullptr;
+    };
+
+    // Returns 1 = done, 0 = declined (caller uses the LSD path), 2 = the input holds more records than one
+    // pass takes (*too_big set): run_all splits it into ranges of the prefix space.
     int run(const bbk_reads *rd, const void *d_keys, const uint32_t *d_vals, uint64_t n_in, bool with_mask,
-            MsdOutput &out, int sel_bits = 0, uint32_t sel_val = 0, int *need_sel_bits = nullptr) {
+            MsdOutput &out, Sel sel = Sel(), bool *too_big = nullptr, Dst dst = Dst()) {
         constexpr uint32_t kPartTileK = PartCfg<W>::TILE;
         const bool from_reads = rd != nullptr;
         const bool has_val = with_mask || d_vals != nullptr;
@@ -1954,29 +1975,32 @@ struct MsdRunner {
         }
         out.instances = N;
         out.n = 0;
+        const bool has_dst = dst.keys != nullptr;
+        auto empty_out = [&]() {
+            if (!has_dst) {
+                out.keys.alloc(16);
+                out.vals.alloc(16);
+            }
+        };
         if (N == 0) {
-            out.keys.alloc(16);
-            out.vals.alloc(16);
+            empty_out();
             return 1;
         }
-        if (sel_bits == 0 && from_reads && dmode == MSD_HASH && N > pass_limit() && need_sel_bits) {
-            int bits = 1;
-            while ((N >> bits) > pass_limit() && bits < 8) ++bits;
-            *need_sel_bits = bits;
+        const bool ranged = sel.span != 0;
+        if (!ranged && N > pass_limit(from_reads) && too_big) {
+            *too_big = true;
             return 2;
         }
         const uint64_t Ntot = N;        // instance space of the level-1 tiles
-        if (sel_bits) N = (N >> sel_bits) + (N >> (sel_bits + 4)) + 1;  // planning estimate of this range's share
-        // record offsets inside one pass are 32-bit; the reads of a call may hold more (hash-range passes walk
-        // the 64-bit chunk space of the reads once per range)
+        if (ranged) N = sel.est;        // planning estimate of this range's share (exact for KEYS / REF ranges)
+        // record offsets inside one pass are 32-bit; the input of a call may hold more (range passes walk the
+        // 64-bit instance space once per range)
         BBK_REQUIRE(N < (1ull << 32) - kPartTileK, BBK_ERR_ARG,
                     "batch holds %llu records%s; one pass is limited to 2^32-1 (split the input)",
-                    (unsigned long long)N, sel_bits ? " in one of 256 hash ranges" : "");
+                    (unsigned long long)N, ranged ? " in one range of the prefix space" : "");
 
         // ---- bin plan: nb1 (power of two) level-1 bins; level-2 bin counts are chosen per segment below
-        // key arrays deduplicated through the LDS hash table (merge of received shards: multiplicity 1..nranks) are
-        // nearly all distinct: keep the table's load around 0.5 there
-        const double fill = (!from_reads && use_hash_dedup()) ? 0.52 : kBucketFill;
+        const double fill = plan_fill(from_reads);
         const double target = fill * bucket_cap();
         const double want = std::max(1.0, std::ceil((double)N / target));
         uint32_t nb1 = 1;
@@ -1985,16 +2009,21 @@ struct MsdRunner {
             nb1 <<= 1;
             ++b1;
         }
-        if (dmode == MSD_REF && b1 < 4) {  // the 4 bucket bits must be consumed by level 1: a bucket (sorted by key
-            b1 = 4;                        // alone) may not hold records of two XXH3 buckets
-            nb1 = 16;
+        // REF prefix: the 4 XXH3 bucket bits must be consumed before the buckets (a bucket is sorted by key alone
+        // and may not hold records of two XXH3 buckets) -- by the range selection (a range inside one XXH3 bucket
+        // shifts them all out: shl >= 4; run_all only makes wider ranges as aligned groups of 2^j whole buckets,
+        // shl = 4 - j) and, for what is left, by level 1
+        const int ref_bits = dmode == MSD_REF ? std::max(0, 4 - (ranged ? sel.shl : 0)) : 0;
+        if (b1 < ref_bits) {
+            b1 = ref_bits;
+            nb1 = 1u << b1;
         }
         const bool verbose = getenv("BBK_VERBOSE") != nullptr;
         if (want / nb1 > 0.75 * kMaxBins) {  // would need a third level: leave to the LSD path
             if (verbose) fprintf(stderr, "[bbk] msd declines: N=%llu needs more than two levels\n", (unsigned long long)N);
             return 0;
         }
-        PartLevel L1{1, b1, nb1, dmode, w0bits, nullptr, nullptr, sel_bits, sel_val};
+        PartLevel L1{1, b1, nb1, dmode, w0bits, nullptr, nullptr, sel.lo, sel.span, sel.shl};
 
         // level-1 tiles cover the whole instance space; a range pass keeps its share of every tile.  Reads:
         // a tile is `threads` chunks, so the histogram (512 threads) and the scatter (1024) have their own tables
@@ -2032,7 +2061,7 @@ struct MsdRunner {
         // below on a key array.  Heavy repeats therefore cost a second pass over a small part of the data.
         const char *smin = getenv("BBK_SLOTS_MIN");  // tests lower it to run the slot mode on small inputs
         const uint64_t slots_min = smin ? strtoull(smin, nullptr, 10) : (1ull << 22);
-        const bool slots = slots_ok && dmode == MSD_HASH && (use_hash_dedup() || use_hashidx_dedup()) && nb1 > 1 &&
+        const bool slots = slots_ok && !has_dst && dmode == MSD_HASH && (use_hash_dedup() || use_hashidx_dedup()) && nb1 > 1 &&
                            N >= slots_min && (double)N / fill * 1.1 + (double)N < 4.2e9;  // u32 slot offsets
         const uint32_t seg_cap = slots ? ((uint32_t)((double)N / nb1 * 1.01) + 8192u) | 1u : 0u;
         const uint32_t cap2 = bucket_cap();
@@ -2062,7 +2091,7 @@ struct MsdRunner {
         std::vector<uint32_t> over_seg;  // slot mode: segments that ran over (reprocessed as a whole)
         if (!slots) {
             BBK_HIP(hipMemsetAsync(hist1.p, 0, (size_t)nb1 * 4 + 16, ctx->stream));
-            if (nb1 > 1 || sel_bits) {
+            if (nb1 > 1 || ranged) {
                 const double hb = from_reads ? (double)rd->n_words * 8 : (double)N * rec;
                 if (from_reads) {
                     launch_part_reads<false, true>("part_hist1_reads", hb, ntiles1h, Sh, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
@@ -2077,15 +2106,14 @@ struct MsdRunner {
             BBK_HIP(hipStreamSynchronize(ctx->stream));
             off1[0] = 0;
             for (uint32_t b = 0; b < nb1; ++b) off1[b + 1] = off1[b] + h1[b];
-            if (sel_bits) {
-                N = off1[nb1];  // the records of this hash range
+            if (ranged) {
+                N = off1[nb1];  // the records of this range
                 out.instances = N;
             }
             BBK_REQUIRE(off1[nb1] == (uint32_t)N, BBK_ERR_INTERNAL, "level-1 histogram does not add up (%u vs %llu)",
                         off1[nb1], (unsigned long long)N);
             if (N == 0) {
-                out.keys.alloc(16);
-                out.vals.alloc(16);
+                empty_out();
                 return 1;
             }
         } else {
@@ -2125,15 +2153,14 @@ struct MsdRunner {
                     h1[b] = reserved;
                 }
             }
-            if (sel_bits) {
+            if (ranged) {
                 N = got;
                 out.instances = N;
             }
             BBK_REQUIRE(got == N, BBK_ERR_INTERNAL, "level-1 reservations do not add up (%llu vs %llu)",
                         (unsigned long long)got, (unsigned long long)N);
             if (N == 0) {
-                out.keys.alloc(16);
-                out.vals.alloc(16);
+                empty_out();
                 return 1;
             }
         }
@@ -2154,7 +2181,7 @@ struct MsdRunner {
         BBK_HIP(hipMemcpyAsync(seg_nb2.p, snb2.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(seg_bin.p, sbin.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(seg_size.p, h1.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
-        PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), sel_bits, sel_val};
+        PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), sel.lo, sel.span, sel.shl};
         const uint32_t ntiles2 = tstart[nb1];
         TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), seg_size.as<uint32_t>(), nb1, N, ntiles2, 1, nullptr, 0, 0};
         DevBuf desc2((size_t)ntiles2 * sizeof(uint4) + 16);
@@ -2225,12 +2252,14 @@ struct MsdRunner {
                             getenv("BBK_NO_DIRECT") == nullptr;
         DevBuf dupf;
         if (direct) {
-            out.keys.alloc(N * rec + 16);
-            if (out_vals) out.vals.alloc(N * 4 + 16);
+            if (!has_dst) {
+                out.keys.alloc(N * rec + 16);
+                if (out_vals) out.vals.alloc(N * 4 + 16);
+            }
             dupf.alloc(16);
             BBK_HIP(hipMemsetAsync(dupf.p, 0, 16, ctx->stream));
-            A.sorted_keys = out.keys.p;
-            A.sorted_vals = out.vals.as<uint32_t>();
+            A.sorted_keys = has_dst ? dst.keys : out.keys.p;
+            A.sorted_vals = has_dst ? dst.vals : out.vals.as<uint32_t>();
             A.dup_flag = dupf.as<uint32_t>();
             A.strip_mask = strip_mask;
         }
@@ -2266,8 +2295,10 @@ struct MsdRunner {
                 return 1;
             }
             if (verbose) fprintf(stderr, "[bbk] msd direct output withdrawn (flagged=%u dup=%u): in-place pass\n", ctr[2], ctr[3]);
-            out.keys.release();
-            out.vals.release();
+            if (!has_dst) {
+                out.keys.release();
+                out.vals.release();
+            }
             A.sorted_keys = nullptr;
             A.sorted_vals = nullptr;
             A.dup_flag = nullptr;
@@ -2303,7 +2334,21 @@ struct MsdRunner {
                 return 3;
             }
             const std::vector<uint32_t> &over_bkt = flagged;
-            const uint64_t n_extra = (uint64_t)n_spill + (uint64_t)over_seg.size() * seg_cap + (uint64_t)over_bkt.size() * cap2;
+            // records a flagged bucket's slot really holds: a bucket is also flagged when its LDS table gives up on a
+            // slot that is NOT full (more distinct keys than the table takes), and the rest of such a slot is stale
+            // pool memory -- never copy more than the level-2 cursor says was written
+            std::vector<uint32_t> bkt_fill(over_bkt.size(), cap2);
+            if (!over_bkt.empty()) {
+                std::vector<uint32_t> cur2(nbuckets);
+                BBK_HIP(hipMemcpyAsync(cur2.data(), hist2.p, (size_t)nbuckets * 4, hipMemcpyDeviceToHost, ctx->stream));
+                BBK_HIP(hipStreamSynchronize(ctx->stream));
+                for (size_t i = 0; i < over_bkt.size(); ++i) {
+                    const uint32_t g = over_bkt[i];
+                    bkt_fill[i] = std::min<uint32_t>(cap2, cur2[g] - g * stride2);
+                }
+            }
+            uint64_t n_extra = (uint64_t)n_spill + (uint64_t)over_seg.size() * seg_cap;
+            for (uint32_t f : bkt_fill) n_extra += f;
             if (verbose)
                 fprintf(stderr, "[bbk] msd slots N=%llu nb1=%u seg_cap=%u buckets=%u spill=%u over_seg=%zu over_bkt=%zu\n",
                         (unsigned long long)N, nb1, seg_cap, nbuckets, n_spill, over_seg.size(), over_bkt.size());
@@ -2329,7 +2374,8 @@ struct MsdRunner {
                 };
                 put(spill_k.p, spill_v.as<uint32_t>(), 0, n_spill);
                 for (uint32_t b : over_seg) put(bufA.p, valA.as<uint32_t>(), (uint64_t)b * seg_cap, seg_cap);
-                for (uint32_t b : over_bkt) put(bufB.p, valB.as<uint32_t>(), (uint64_t)b * stride2, cap2);
+                for (size_t i = 0; i < over_bkt.size(); ++i)
+                    put(bufB.p, valB.as<uint32_t>(), (uint64_t)over_bkt[i] * stride2, bkt_fill[i]);
                 if (tiny) {
                     // the usual case (one or two crowded buckets): ONE workgroup sorts + reduces all of it in LDS,
                     // instead of a whole partition pipeline for a few thousand records
@@ -2450,18 +2496,22 @@ struct MsdRunner {
             check_launch("k_u32_to_u64");
             D = exclusive_scan_u64(ctx, d64.as<uint64_t>(), d64.as<uint64_t>(), nbuckets);
             out.n = D;
-            out.keys.alloc(out.n * rec + 16);
-            if (out_vals) out.vals.alloc(out.n * 4 + 16);
+            if (!has_dst) {
+                out.keys.alloc(out.n * rec + 16);
+                if (out_vals) out.vals.alloc(out.n * 4 + 16);
+            }
+            Key<W> *ck = has_dst ? (Key<W> *)dst.keys : out.keys.as<Key<W>>();
+            uint32_t *cv = has_dst ? dst.vals : out.vals.as<uint32_t>();
             KernelTimer t(ctx, "compact", 2.0 * (double)D * (rec + (out_vals ? 4 : 0)));
             const unsigned blocks = (unsigned)(((uint64_t)nbuckets * 64 + 255) / 256);
             if (out_vals)
                 hipLaunchKernelGGL((k_compact<W, true>), dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<Key<W>>(),
                                    valB.as<uint32_t>(), boff.as<uint32_t>(), dcount.as<uint32_t>(), d64.as<uint64_t>(),
-                                   nbuckets, out.keys.as<Key<W>>(), out.vals.as<uint32_t>(), strip_mask, 0u);
+                                   nbuckets, ck, cv, strip_mask, 0u);
             else
                 hipLaunchKernelGGL((k_compact<W, false>), dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<Key<W>>(),
                                    (const uint32_t *)nullptr, boff.as<uint32_t>(), dcount.as<uint32_t>(),
-                                   d64.as<uint64_t>(), nbuckets, out.keys.as<Key<W>>(), (uint32_t *)nullptr, strip_mask,
+                                   d64.as<uint64_t>(), nbuckets, ck, (uint32_t *)nullptr, strip_mask,
                                    0u);
             check_launch("k_compact");
         }
@@ -2484,31 +2534,192 @@ struct MsdRunner {
         return 1;
     }
 
-    // run() plus the split into hash ranges when the reads hold more records than one pass takes: every
-    // range is deduplicated on its own (disjoint key sets), the distinct records are concatenated.
+    // Histogram of the whole input over the top `bits` bits of the prefix (key arrays, KEYS / REF prefix): the
+    // range passes of run_all are sized from it, so a skewed key space still gives passes that fit.
+    std::vector<uint64_t> prefix_histogram(const void *d_keys, uint64_t n_records, int bits) {
+        constexpr uint32_t kPartTileK = PartCfg<W>::TILE;
+        const uint32_t nb = 1u << bits;
+        const int w0bits = (W == 1) ? (int)(2 * k) : 64;
+        DevBuf h((size_t)nb * 4 + 16);
+        BBK_HIP(hipMemsetAsync(h.p, 0, (size_t)nb * 4 + 16, ctx->stream));
+        PartLevel L{1, bits, nb, dmode, w0bits, nullptr, nullptr, 0u, 0u, 0};
+        TileMap M{nullptr, nullptr, nullptr, 1, n_records, 0, 1, nullptr, (int)expand_k, expand_tag ? 1 : 0};
+        const uint64_t nt = (n_records + kPartTileK - 1) / kPartTileK;
+        BBK_REQUIRE(nt < (1ull << 32), BBK_ERR_ARG, "input of %llu records exceeds the tile space", (unsigned long long)n_records);
+        const size_t rec = (size_t)W * 8;
+        launch_part<false, true>("part_hist0", (double)(expand_k ? n_records / 2 : n_records) * rec, (uint32_t)nt,
+                                 (const Key<W> *)d_keys, nullptr, M, L, h.as<uint32_t>(), nullptr, nullptr, nullptr);
+        std::vector<uint32_t> h32(nb);
+        BBK_HIP(hipMemcpyAsync(h32.data(), h.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        std::vector<uint64_t> out(nb);
+        uint64_t tot = 0;
+        for (uint32_t i = 0; i < nb; ++i) tot += (out[i] = h32[i]);
+        // a 32-bit counter that wrapped (one fine range above 2^32 records) shows up here
+        BBK_REQUIRE(tot == n_records, BBK_ERR_ARG,
+                    "key space too skewed for range passes (%llu of %llu records counted)", (unsigned long long)tot,
+                    (unsigned long long)n_records);
+        return out;
+    }
+
+    // Ranges of the prefix space for an input above one pass.  HASH: 2^b equal hash ranges (uniform whatever the
+    // input).  KEYS / REF: consecutive fine ranges (1/512 of the prefix space) grouped up to the pass limit from
+    // an exact histogram; REF additionally never lets a range straddle XXH3 buckets except as an aligned group of
+    // 2^j whole buckets (see ref_bits in run()).
+    bool plan_ranges(const bbk_reads *rd, const void *d_keys, uint64_t N, std::vector<Sel> &ranges) {
+        const uint64_t limit = (uint64_t)((double)pass_limit(rd != nullptr) * 0.92);
+        const bool verbose = getenv("BBK_VERBOSE") != nullptr;
+        ranges.clear();
+        if (dmode == MSD_HASH) {
+            int bits = 1;
+            while ((N >> bits) > limit && bits < 12) ++bits;
+            if ((N >> bits) > limit) return false;
+            for (uint32_t v = 0; v < (1u << bits); ++v) {
+                Sel s;
+                s.lo = v << (32 - bits);
+                s.span = 1u << (32 - bits);
+                s.shl = bits;
+                s.est = (N >> bits) + (N >> (bits + 4)) + 1;
+                ranges.push_back(s);
+            }
+            if (verbose) fprintf(stderr, "[bbk] msd: %llu records in %zu hash ranges\n", (unsigned long long)N, ranges.size());
+            return true;
+        }
+        BBK_REQUIRE(rd == nullptr, BBK_ERR_INTERNAL, "reads are partitioned by hash prefix only");
+        constexpr int FB = 9;  // fine ranges: 512 (the level-1 histogram kernel's bin limit)
+        const std::vector<uint64_t> h = prefix_histogram(d_keys, N, FB);
+        auto emit = [&](uint32_t f0, uint32_t f1, uint64_t cnt) {  // fine ranges [f0, f1)
+            Sel s;
+            s.lo = f0 << (32 - FB);
+            const uint64_t span = (uint64_t)(f1 - f0) << (32 - FB);
+            if (span >= (1ull << 32)) {  // everything (cannot happen for an input above the limit, kept for safety)
+                s.span = 0;
+                s.shl = 0;
+            } else {
+                s.span = (uint32_t)span;
+                s.shl = __builtin_clz((uint32_t)span - 1u);  // span <= 2^(32 - shl)
+            }
+            s.est = cnt;
+            if (cnt) ranges.push_back(s);
+        };
+        auto greedy = [&](uint32_t f0, uint32_t f1) -> bool {  // groups the fine ranges [f0, f1)
+            uint32_t g0 = f0;
+            uint64_t acc = 0;
+            for (uint32_t f = f0; f < f1; ++f) {
+                if (h[f] > limit) return false;
+                if (acc + h[f] > limit) {
+                    emit(g0, f, acc);
+                    g0 = f;
+                    acc = 0;
+                }
+                acc += h[f];
+            }
+            emit(g0, f1, acc);
+            return true;
+        };
+        bool ok = true;
+        if (dmode == MSD_KEYS) {
+            ok = greedy(0, 1u << FB);
+        } else {  // MSD_REF: fine ranges 32 x b .. 32 x b + 31 make up XXH3 bucket b
+            constexpr uint32_t per = (1u << FB) / 16;
+            uint64_t bt[16];
+            for (int b = 0; b < 16; ++b) {
+                bt[b] = 0;
+                for (uint32_t f = 0; f < per; ++f) bt[b] += h[b * per + f];
+            }
+            int g = 8;  // largest aligned group of whole buckets that fits a pass
+            for (; g >= 1; g >>= 1) {
+                bool fits = true;
+                for (int b = 0; b < 16 && fits; b += g) {
+                    uint64_t t = 0;
+                    for (int j = 0; j < g; ++j) t += bt[b + j];
+                    fits = t <= limit;
+                }
+                if (fits) break;
+            }
+            if (g >= 1) {
+                for (int b = 0; b < 16; b += g) {
+                    uint64_t t = 0;
+                    for (int j = 0; j < g; ++j) t += bt[b + j];
+                    emit((uint32_t)b * per, (uint32_t)(b + g) * per, t);
+                }
+            } else {
+                for (int b = 0; b < 16 && ok; ++b) ok = greedy((uint32_t)b * per, (uint32_t)(b + 1) * per);
+            }
+        }
+        if (verbose) {
+            fprintf(stderr, "[bbk] msd: %llu records, prefix mode %d, %zu key ranges%s:", (unsigned long long)N, dmode,
+                    ranges.size(), ok ? "" : " (a fine range exceeds one pass)");
+            for (const Sel &r : ranges) fprintf(stderr, " %llu", (unsigned long long)r.est);
+            fprintf(stderr, "\n");
+        }
+        return ok;
+    }
+
+    // run() plus the split into ranges of the prefix space when the input holds more records than one pass takes
+    // (what the reference does with bounded buffers, repeated DumpBuffers rounds and the run merge,
+    // kmer_splitter.hpp:73-167, kmer_index_builder.hpp:281-365).  HASH prefix: every hash range is deduplicated on
+    // its own (disjoint key sets) and the distinct records are concatenated.  KEYS / REF prefix: the ranges are
+    // consecutive in prefix order and every pass writes straight into the final array.
     bool run_all(const bbk_reads *rd, const void *d_keys, const uint32_t *d_vals, uint64_t n_in, bool with_mask,
                  MsdOutput &out) {
-        int bits = 0;
-        int r = run(rd, d_keys, d_vals, n_in, with_mask, out, 0, 0, &bits);
+        bool too_big = false;
+        int r = run(rd, d_keys, d_vals, n_in, with_mask, out, Sel(), &too_big);
         if (r == 3) {  // the slot mode gave up (too much of the input overflowed its slots): exact histograms
             slots_ok = false;
-            r = run(rd, d_keys, d_vals, n_in, with_mask, out, 0, 0, &bits);
+            r = run(rd, d_keys, d_vals, n_in, with_mask, out, Sel(), &too_big);
         }
         if (r != 2) return r == 1;
         const size_t rec = (size_t)W * 8;
         const bool out_vals = op != MSD_OP_NONE;
-        std::vector<MsdOutput> parts((size_t)1 << bits);
+        const uint64_t Nrec = out.instances;  // records of the whole input (run() counted them before it returned 2)
+        std::vector<Sel> ranges;
+        if (!plan_ranges(rd, d_keys, Nrec, ranges)) return false;
         uint64_t D = 0, inst = 0;
-        for (uint32_t v = 0; v < (1u << bits); ++v) {
-            int rv = run(rd, nullptr, nullptr, 0, with_mask, parts[v], bits, v, nullptr);
+        if (dmode != MSD_HASH) {
+            // ordered output: one array for all passes (upper bound: every record distinct, which is the usual case --
+            // stage B sorts a distinct set)
+            out.keys.alloc(Nrec * rec + 16);
+            if (out_vals) out.vals.alloc(Nrec * 4 + 16);
+            for (const Sel &sr : ranges) {
+                MsdOutput part;
+                Dst dst{out.keys.as<char>() + D * rec, out_vals ? out.vals.as<uint32_t>() + D : nullptr};
+                const int rv = run(rd, d_keys, d_vals, n_in, with_mask, part, sr, nullptr, dst);
+                if (rv != 1) return false;
+                D += part.n;
+                inst += part.instances;
+            }
+            BBK_REQUIRE(inst == Nrec, BBK_ERR_INTERNAL, "range passes saw %llu of %llu records", (unsigned long long)inst,
+                        (unsigned long long)Nrec);
+            out.n = D;
+            out.instances = Nrec;
+            out.nbuckets = 0;
+            return true;
+        }
+        std::vector<MsdOutput> parts(ranges.size());
+        for (size_t v = 0; v < ranges.size(); ++v) {
+            MsdOutput &pt = parts[v];
+            int rv = run(rd, d_keys, d_vals, n_in, with_mask, pt, ranges[v], nullptr);
             if (rv == 3) {
                 slots_ok = false;
-                rv = run(rd, nullptr, nullptr, 0, with_mask, parts[v], bits, v, nullptr);
+                rv = run(rd, d_keys, d_vals, n_in, with_mask, pt, ranges[v], nullptr);
             }
             if (rv != 1) return false;
-            D += parts[v].n;
-            inst += parts[v].instances;
-            parts[v].bucket_off.release();
+            D += pt.n;
+            inst += pt.instances;
+            pt.bucket_off.release();
+            // the slot mode sizes a part for the worst case (every record distinct): keep what is used
+            if (pt.keys.bytes > pt.n * rec + (64u << 20)) {
+                DevBuf ek(pt.n * rec + 16), ev;
+                BBK_HIP(hipMemcpyAsync(ek.p, pt.keys.p, pt.n * rec, hipMemcpyDeviceToDevice, ctx->stream));
+                if (out_vals) {
+                    ev.alloc(pt.n * 4 + 16);
+                    BBK_HIP(hipMemcpyAsync(ev.p, pt.vals.p, pt.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                }
+                BBK_HIP(hipStreamSynchronize(ctx->stream));
+                pt.keys = std::move(ek);
+                if (out_vals) pt.vals = std::move(ev);
+            }
         }
         out.n = D;
         out.instances = inst;
@@ -2524,8 +2735,10 @@ struct MsdRunner {
                                            ctx->stream));
             }
             o += p.n;
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+            p.keys.release();  // hand the part back before the next copy: peak = result + one part
+            p.vals.release();
         }
-        BBK_HIP(hipStreamSynchronize(ctx->stream));
         out.nbuckets = 0;
         return true;
     }

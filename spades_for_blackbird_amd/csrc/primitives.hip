@@ -740,8 +740,8 @@ static uint64_t unique_impl(bbk_ctx *ctx, const Key<W> *keys, const uint32_t *va
 }
 
 template <int W>
-static uint64_t drop_zero_impl(bbk_ctx *ctx, const Key<W> *keys, const uint32_t *vals, uint64_t n, Key<W> *out_keys,
-                               uint32_t *out_vals) {
+static uint64_t drop_zero_impl(bbk_ctx *ctx, const Key<W> *keys, const uint32_t *vals, uint64_t n, DevBuf &ok,
+                               DevBuf &ov) {
     if (n == 0) return 0;
     const uint64_t nb = (n + kUniqTile - 1) / kUniqTile;
     DevBuf bc(nb * sizeof(uint64_t));
@@ -749,23 +749,25 @@ static uint64_t drop_zero_impl(bbk_ctx *ctx, const Key<W> *keys, const uint32_t 
                        bc.as<uint64_t>());
     check_launch("k_nonzero_count");
     const uint64_t kept = exclusive_scan_u64(ctx, bc.as<uint64_t>(), bc.as<uint64_t>(), nb);
-    if (kept == n) return n;  // nothing to drop: caller keeps its buffers
+    if (kept == n) return n;  // nothing to drop: caller keeps its buffers (the usual case: nothing is allocated)
+    ok.alloc(kept * sizeof(Key<W>) + 16);
+    ov.alloc(kept * 4 + 16);
     hipLaunchKernelGGL(k_nonzero_compact<W>, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream, keys, vals, n,
-                       bc.as<uint64_t>(), out_keys, out_vals);
+                       bc.as<uint64_t>(), ok.as<Key<W>>(), ov.as<uint32_t>());
     check_launch("k_nonzero_compact");
     BBK_HIP(hipStreamSynchronize(ctx->stream));
     return kept;
 }
 
-// Compacts the (key, val) pairs with val != 0 into out_*; returns how many were kept (if all are
-// kept nothing is written).
-uint64_t drop_zero_vals(bbk_ctx *ctx, int W, const void *keys, const uint32_t *vals, uint64_t n, void *out_keys,
-                        uint32_t *out_vals) {
+// Compacts the (key, val) pairs with val != 0 into out_* (allocated here, only when something is dropped); returns
+// how many were kept (if all are kept nothing is allocated or written).
+uint64_t drop_zero_vals(bbk_ctx *ctx, int W, const void *keys, const uint32_t *vals, uint64_t n, DevBuf &out_keys,
+                        DevBuf &out_vals) {
     switch (W) {
-        case 1: return drop_zero_impl<1>(ctx, (const Key<1> *)keys, vals, n, (Key<1> *)out_keys, out_vals);
-        case 2: return drop_zero_impl<2>(ctx, (const Key<2> *)keys, vals, n, (Key<2> *)out_keys, out_vals);
-        case 3: return drop_zero_impl<3>(ctx, (const Key<3> *)keys, vals, n, (Key<3> *)out_keys, out_vals);
-        case 4: return drop_zero_impl<4>(ctx, (const Key<4> *)keys, vals, n, (Key<4> *)out_keys, out_vals);
+        case 1: return drop_zero_impl<1>(ctx, (const Key<1> *)keys, vals, n, out_keys, out_vals);
+        case 2: return drop_zero_impl<2>(ctx, (const Key<2> *)keys, vals, n, out_keys, out_vals);
+        case 3: return drop_zero_impl<3>(ctx, (const Key<3> *)keys, vals, n, out_keys, out_vals);
+        case 4: return drop_zero_impl<4>(ctx, (const Key<4> *)keys, vals, n, out_keys, out_vals);
         default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %d", W);
     }
     return 0;

@@ -206,6 +206,8 @@ extern "C" int bbk_extindex_clip_tips(bbk_ctx *ctx, bbk_extindex *x, uint32_t le
                                       uint64_t *removed_links) {
     return guarded([&] {
         BBK_REQUIRE(ctx && x, BBK_ERR_ARG, "bbk_extindex_clip_tips: NULL argument");
+        BBK_REQUIRE(x->n < (1ull << 32), BBK_ERR_ARG, "bbk_extindex_clip_tips: %llu k-mers exceed the 32-bit k-mer index",
+                    (unsigned long long)x->n);
         BBK_HIP(hipSetDevice(ctx->device));
         if (removed_kmers) *removed_kmers = 0;
         if (removed_links) *removed_links = 0;

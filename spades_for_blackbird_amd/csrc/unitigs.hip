@@ -806,6 +806,9 @@ int bbk_unitigs_export_kc(bbk_ctx *ctx, const bbk_unitigs *u, uint64_t *h_kc) {
 int bbk_unitigs_build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs **out) {
     return guarded([&] {
         BBK_REQUIRE(ctx && x && out, BBK_ERR_ARG, "bbk_unitigs_build: NULL argument");
+        BBK_REQUIRE(x->n < (1ull << 32), BBK_ERR_ARG,
+                    "bbk_unitigs_build: %llu k-mers; the graph stage indexes k-mers, start edges and link records with "
+                    "32 bits (shard the extension index)", (unsigned long long)x->n);
         BBK_HIP(hipSetDevice(ctx->device));
         auto u = std::make_unique<bbk_unitigs>();
         build(ctx, x, *u);

@@ -17,7 +17,9 @@ SYMBOLS = [
     "bbk_reads_from_ascii", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_from_spades_binary",
     "bbk_reads_write_spades_binary", "bbk_reads_count", "bbk_reads_bases",
     "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
-    "bbk_count", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_kmerset_both_strands_ex", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k", "bbk_kmerset_keys", "bbk_reads_median_filter",
+    "bbk_count", "bbk_count_begin", "bbk_count_push_reads", "bbk_count_push_ascii", "bbk_count_finish", "bbk_count_abort",
+    "bbk_count_pushed_instances", "bbk_extindex_begin", "bbk_extindex_push_reads", "bbk_extindex_finish",
+    "bbk_extindex_abort", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_kmerset_both_strands_ex", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k", "bbk_kmerset_keys", "bbk_reads_median_filter",
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_clip_tips", "bbk_extindex_free",
@@ -69,6 +71,17 @@ def load_library():
     L.bbk_reads_export_ascii.argtypes = [vp, vp, vp, vp, u64]
     L.bbk_reads_free.argtypes = [vp]
     L.bbk_count.argtypes = [vp, vp, C.c_uint, C.c_uint, C.POINTER(vp)]
+    L.bbk_count_begin.argtypes = [vp, C.c_uint, C.c_uint, C.POINTER(vp)]
+    L.bbk_count_push_reads.argtypes = [vp, vp]
+    L.bbk_count_push_ascii.argtypes = [vp, C.c_char_p, vp, u64]
+    L.bbk_count_finish.argtypes = [vp, C.POINTER(vp)]
+    L.bbk_count_abort.argtypes = [vp]
+    L.bbk_count_pushed_instances.restype = u64
+    L.bbk_count_pushed_instances.argtypes = [vp]
+    L.bbk_extindex_begin.argtypes = [vp, C.c_uint, C.POINTER(vp)]
+    L.bbk_extindex_push_reads.argtypes = [vp, vp]
+    L.bbk_extindex_finish.argtypes = [vp, C.POINTER(vp)]
+    L.bbk_extindex_abort.argtypes = [vp]
     L.bbk_kmerset_from_device.argtypes = [vp, vp, vp, u64, C.c_uint, C.POINTER(vp)]
     L.bbk_kmerset_from_device_ex.argtypes = [vp, vp, vp, u64, C.c_uint, C.c_uint, C.POINTER(vp)]
     L.bbk_kmerset_both_strands.argtypes = [vp, vp, C.POINTER(vp)]
@@ -209,6 +222,14 @@ class Context:
         _check(self._L.bbk_count(self._h, reads._h, k, flags, C.byref(h)))
         return KMerSet(self, h)
 
+    def counter(self, k, flags=BOTH_STRANDS):
+        """Streaming count (bbk_count_begin / push / finish): KMerSortingSplitter's bounded rounds + MergeKMers."""
+        return Counter(self, k, flags)
+
+    def extbuilder(self, k):
+        """Streaming extension-index build (bbk_extindex_begin / push / finish)."""
+        return ExtBuilder(self, k)
+
     def kmerset_from_device(self, d_keys, n, k, d_counts=None, flags=0):
         h = C.c_void_p()
         _check(self._L.bbk_kmerset_from_device_ex(self._h, _ptr(d_keys), _ptr(d_counts), n, k, flags, C.byref(h)))
@@ -343,6 +364,77 @@ class KMerSet(_Handle):
 
     def write_final_kmers(self, path):
         _check(self._L.bbk_kmerset_write_final_kmers(self.ctx._h, self._h, path.encode()))
+
+
+class Counter:
+    """bbk_counter: push batches of reads, finish() returns the KMerSet (and releases the counter)."""
+
+    def __init__(self, ctx, k, flags):
+        self.ctx, self._L = ctx, ctx._L
+        h = C.c_void_p()
+        _check(self._L.bbk_count_begin(ctx._h, k, flags, C.byref(h)))
+        self._h = h
+
+    def push(self, reads):
+        _check(self._L.bbk_count_push_reads(self._h, reads._h))
+
+    def push_ascii(self, reads):
+        bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+        offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+        if bs:
+            offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        _check(self._L.bbk_count_push_ascii(self._h, b"".join(bs), _ptr(offs), len(bs)))
+
+    @property
+    def instances(self):
+        return int(self._L.bbk_count_pushed_instances(self._h))
+
+    def finish(self):
+        h = C.c_void_p()
+        c, self._h = self._h, None
+        _check(self._L.bbk_count_finish(c, C.byref(h)))
+        return KMerSet(self.ctx, h)
+
+    def abort(self):
+        if getattr(self, "_h", None):
+            self._L.bbk_count_abort(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.abort()
+        except Exception:
+            pass
+
+
+class ExtBuilder:
+    """bbk_extbuilder: push batches of reads, finish() returns the ExtIndex."""
+
+    def __init__(self, ctx, k):
+        self.ctx, self._L = ctx, ctx._L
+        h = C.c_void_p()
+        _check(self._L.bbk_extindex_begin(ctx._h, k, C.byref(h)))
+        self._h = h
+
+    def push(self, reads):
+        _check(self._L.bbk_extindex_push_reads(self._h, reads._h))
+
+    def finish(self):
+        h = C.c_void_p()
+        b, self._h = self._h, None
+        _check(self._L.bbk_extindex_finish(b, C.byref(h)))
+        return ExtIndex(self.ctx, h)
+
+    def abort(self):
+        if getattr(self, "_h", None):
+            self._L.bbk_extindex_abort(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.abort()
+        except Exception:
+            pass
 
 
 class ExtIndex(_Handle):

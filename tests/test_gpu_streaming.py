@@ -1,0 +1,110 @@
+"""GPU: the streaming entry points (bbk_count_begin / push / finish, bbk_extindex_begin / push / finish) and the
+range passes of both stages.
+
+What the reference gets from bounded cells + repeated DumpBuffers rounds + MergeKMers
+(common/utils/kmer_mph/kmer_splitter.hpp:73-167, kmer_index_builder.hpp:281-365) must give the same bytes as one
+pass over everything: the same reads pushed in >= 3 batches (a merge forced after every push, every stage forced
+into range passes by a tiny BBK_PASS_LIMIT) have to produce byte-identical final_kmers and extension index to the
+one-shot calls and to the oracle, for all four key widths.  The knobs are read once per process, hence subprocesses.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(bool(os.environ.get("BBK_DISABLE_MSD")), reason="tests of the MSD path's modes")]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import numpy as np, sys
+sys.path.insert(0, %(root)r)
+import spades_for_blackbird_amd as B
+from oracle import oracle as O
+from tests.helpers import synth_reads
+ctx = B.Context(0)
+reads = synth_reads(%(n)d, read_len=150, genome_len=%(g)d, sub_rate=0.01, seed=11, n_rate=0.002)
+reads += ["A" * 150] * 40 + ["ACGT" * 37] * 30 + ["AC"] + ["ACGTN" * 30] + [""]
+cuts = [0, len(reads) // 5, len(reads) // 2, len(reads) - 7, len(reads)]
+import re
+runs = [max(re.findall("[ACGTacgt]+", x) or [""], key=len) for x in reads]   # LongestValid
+def n_inst(k):
+    return sum(max(0, len(x) - k + 1) for x in runs)
+for k in %(ks)r:
+    whole = ctx.reads_from_ascii(reads)
+    exp, ec = O.kmercount(reads, k, 16, 2, with_counts=True)
+    # one shot (its stages may themselves run in range passes under the forced limits)
+    one, oc = ctx.count(whole, k, B.BOTH_STRANDS | B.WITH_COUNTS).export(B.ORDER_REFERENCE_BUCKETS16, with_counts=True)
+    assert np.array_equal(one, exp) and np.array_equal(oc, ec), ("one-shot", k)
+    # pushed in 4 batches, with counts
+    c = ctx.counter(k, B.BOTH_STRANDS | B.WITH_COUNTS)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        r = ctx.reads_from_ascii(reads[a:b])
+        c.push(r)
+        r.free()
+    assert c.instances == n_inst(k), ("instances", k)
+    s = c.finish()
+    got, gc = s.export(B.ORDER_REFERENCE_BUCKETS16, with_counts=True)
+    assert np.array_equal(got, exp) and np.array_equal(gc, ec), ("pushed+counts", k)
+    s.free()
+    # pushed as ASCII, final_kmers order built in place, no counts (the spades-kmercount configuration)
+    c = ctx.counter(k, B.BOTH_STRANDS | B.REFERENCE_ORDER)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        c.push_ascii(reads[a:b])
+    s = c.finish()
+    assert np.array_equal(s.export(B.ORDER_REFERENCE_BUCKETS16), exp), ("pushed ref order", k)
+    assert s.instances == 2 * n_inst(k), ("instances both strands", k)
+    s.free()
+    # canonical, ascending
+    c = ctx.counter(k, B.CANONICAL | B.WITH_COUNTS)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        r = ctx.reads_from_ascii(reads[a:b]); c.push(r); r.free()
+    s = c.finish()
+    ck, cc = s.export(B.ORDER_SORTED, with_counts=True)
+    one_c = ctx.count(whole, k, B.CANONICAL | B.WITH_COUNTS)
+    ok, occ = one_c.export(B.ORDER_SORTED, with_counts=True)
+    assert np.array_equal(ck, ok) and np.array_equal(cc, occ), ("canonical", k)
+    if k %% 2 == 1 and k + 1 < 128:
+        ox = O.ExtIndex(reads, k, 1)
+        order = np.lexsort([ox.kmers[:, j] for j in range(ox.kmers.shape[1] - 1, -1, -1)])
+        x1 = ctx.extindex(whole, k)
+        k1, m1 = x1.export()
+        assert np.array_equal(k1, ox.kmers[order]) and np.array_equal(m1, ox.masks[order]), ("ext one-shot", k)
+        xb = ctx.extbuilder(k)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            r = ctx.reads_from_ascii(reads[a:b]); xb.push(r); r.free()
+        x2 = xb.finish()
+        k2, m2 = x2.export()
+        assert np.array_equal(k2, k1) and np.array_equal(m2, m1), ("ext pushed", k)
+    whole.free()
+print("STREAMING-OK")
+"""
+
+
+def _run(env_extra, n, g, ks):
+    env = dict(os.environ, BBK_VERBOSE="1", **env_extra)
+    r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT, "n": n, "g": g, "ks": ks}], capture_output=True,
+                       text=True, env=env, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "STREAMING-OK" in r.stdout
+    return r.stderr
+
+
+def test_pushed_batches_equal_one_shot_all_widths():
+    """merge after every push; default pass limits"""
+    _run({"BBK_MERGE_MIN": "0"}, 2500, 15000, (21, 55, 77, 127))
+
+
+def test_pushed_batches_with_forced_range_passes():
+    """every stage in range passes: hash ranges from reads (stage A) and from key arrays (the merges), key ranges
+    in stage B (KEYS prefix: tagged 8-byte keys and the extension index; REF prefix: 16-byte keys)"""
+    err = _run({"BBK_MERGE_MIN": "0", "BBK_PASS_LIMIT": "30000"}, 2500, 15000, (21, 32, 55, 77))
+    assert "hash ranges" in err and "key ranges" in err
+    assert "prefix mode 2" in err, "the REF-prefix range passes (16-byte keys, final_kmers order) did not run"
+
+
+def test_slot_mode_with_pushed_batches():
+    """the histogram-free slot mode + spill reprocessing on every pushed batch and on the merges"""
+    _run({"BBK_MERGE_MIN": "0", "BBK_SLOTS_MIN": "0"}, 3000, 20000, (21, 33))
