@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the k-mer counting path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--k 21]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--k 21] [--ext-index]
 
 Metric (BASELINE.json): distinct k-mers/sec, k=21, 150 bp synthetic reads.
 N=1 workload = BASELINE.json configs[1]: 10 M x 150 bp uniform reads (50x coverage of a
@@ -9,20 +9,25 @@ N=1 workload = BASELINE.json configs[1]: 10 M x 150 bp uniform reads (50x covera
 One "step" = one full pass of the hot path over the batch: 2-bit extraction of canonical
 k-mers -> hash-partitioned dedup -> both-strand expansion -> sort into the reference
 (final_kmers) order, result left in HBM.  value = |final_kmers records| * N / time.
+`--reads 100000000 --k 55 --ext-index` is BASELINE.json configs[2] (count + DeBruijnExtensionIndex build per step).
 
-N>1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank holds its own
-10 M reads of a common genome that grows with N (weak scaling); ranks count locally, partition
-distinct canonical k-mers by owner hash, exchange them with ONE all_to_all_single (the only
-collective on the data path), merge-unique their shard and expand it to both strands.
+N>1: one rank per GPU over RCCL.  Launched by torch.distributed.run (RANK/WORLD_SIZE in the env) or, when
+`python bench.py --gpus N` is called directly, this process starts the N ranks itself (before touching the GPU) and
+returns their exit code.  Every rank holds its own 10 M reads of a common genome that grows with N (weak scaling);
+ranks count locally, partition distinct canonical k-mers by owner hash, exchange them with ONE all_to_all_single (the
+only collective on the data path), merge-unique their shard and expand it to both strands.
 
-Extra objects on the JSON line: "roofline" for the dominant kernel (the radix scatter pass),
-measured with HIP events on the engine's stream inside the timed region, and "cpu_baseline"
-(the CPU oracle -- a port of the reference's split/sort/unique/merge algorithm -- timed on a
-bounded sample of the same workload on this box's host cores, rank 0 at N=1 only).
+Extra objects on the JSON line (N=1): "roofline" for the dominant kernel, measured with HIP events on the engine's
+stream inside the timed region; "k55": the same step at k=55 (16-byte keys) with its own roofline; "gfa_build": wall
+seconds of extension index -> unitigs -> GFA on the same reads; "e2e": wall seconds of the two CLI binaries
+(spades-kmercount, spades-gbuilder --gfa) on the same reads written as FASTA to tmpfs, with their phases, next to the
+CPU oracle run end to end (parse included) on a bounded sample; "cpu_baseline": the CPU oracle -- a port of the
+reference's split/sort/unique/merge algorithm -- timed on a bounded sample on this box's host cores.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,9 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md), the figure fractions are quoted against
-FAMILIES = ["extract", "hist", "scan", "scatter", "unique", "reduce", "expand", "part_hist1_reads", "part_hist1_keys",
-            "part_scatter1_reads", "part_scatter1_keys", "part_hist2", "part_scatter2", "lds_dedup", "lds_sort",
-            "compact"]
+FAMILIES = ["extract", "hist", "scan", "scatter", "unique", "reduce", "expand", "part_hist0", "part_hist1_reads",
+            "part_hist1_keys", "part_scatter1_reads", "part_scatter1_keys", "part_hist2", "part_scatter2", "lds_dedup",
+            "lds_sort", "compact"]
 # HBM traffic from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate runs of this very
 # command and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py).  A profiler cannot run
 # inside the timed process, so the committed summary is attached when the workload is the one it was
@@ -49,10 +54,30 @@ def parse():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=21)
+    ap.add_argument("--ext-index", action="store_true",
+                    help="a step also builds the extension index (BASELINE configs[2] with --reads 100000000 --k 55)")
     ap.add_argument("--cpu-sample-reads", type=int, default=4_000_000)
+    ap.add_argument("--e2e-cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gfa", action="store_true", help="skip the (untimed-region) GFA-build wall-time measurement")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the CLI wall-time measurement on FASTA input")
+    ap.add_argument("--no-k55", action="store_true", help="skip the k=55 (16-byte keys) object")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (nothing has touched the GPU in this
+    process), hand their output through, return their exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(ctx, args, B):
@@ -72,13 +97,15 @@ def cpu_baseline(ctx, args, B):
         "value": len(out) / dt, "unit": "distinct k-mers/s", "cores": cores, "kind": "port",
         "instances_per_s": inst / dt, "seconds": dt,
         "sample": "%d x %d bp synthetic reads (same generator and 50x coverage as the GPU workload), "
-                  "oracle/bbk_oracle.c orc_kmercount, 16 buckets, OpenMP %d threads" % (n, args.read_len, cores),
+                  "oracle/bbk_oracle.c orc_kmercount, 16 buckets, OpenMP %d threads (the sort phase can use 16: one per "
+                  "bucket, as CountAll(16, ...)); parse not included (see e2e.cpu_port for the end-to-end figure)"
+                  % (n, args.read_len, cores),
     }
 
 
 def gfa_build(ctx, reads, k):
     """Second half of the metric: wall seconds of the spades-gbuilder path on the same reads (extension
-    index -> unitigs + links -> GFA text written to tmpfs), measured once outside the timed region."""
+    index -> unitigs + links -> GFA text written to tmpfs), measured outside the timed region."""
     import tempfile
     ctx.synchronize()
     d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
@@ -101,8 +128,144 @@ def gfa_build(ctx, reads, k):
     return best
 
 
+def write_fasta(reads, path, n=None):
+    """SURVEY 8(d) input format: `>r\\n<bases>\\n` per read (154 B for 150 bp)."""
+    import numpy as np
+    blob, offs = reads.to_ascii()
+    nr = len(offs) - 1 if n is None else n
+    L = int(offs[1] - offs[0]) if nr else 0
+    arr = np.frombuffer(blob, dtype=np.uint8)[: nr * L].reshape(nr, L)
+    out = np.empty((nr, L + 4), dtype=np.uint8)
+    out[:, 0] = ord(">")
+    out[:, 1] = ord("r")
+    out[:, 2] = 10
+    out[:, 3:3 + L] = arr
+    out[:, 3 + L] = 10
+    out.tofile(path)
+    return nr
+
+
+def run_cli(cmd):
+    env = dict(os.environ, BBK_PHASES="1")
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    wall = time.perf_counter() - t0
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-400:], "wall_s": wall}
+    ph = None
+    for line in r.stdout.splitlines():
+        if line.startswith("BBK_PHASES "):
+            ph = json.loads(line[len("BBK_PHASES "):])
+    return {"wall_s": wall, "phases": ph}
+
+
+def e2e(ctx, reads, args):
+    """What north_star's target is stated on: wall time of the two CLIs on FASTA input, beside the CPU path.
+    The GPU step's reads are written as FASTA to tmpfs; the built binaries are run as a user would run them
+    (process start, HIP context creation, parse, upload, device work, download, file write all inside the wall time)."""
+    import tempfile
+    from spades_for_blackbird_amd import build_host
+    k = args.k
+    d = tempfile.mkdtemp(prefix="bbk_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    out = {"input": None}
+    try:
+        fa = os.path.join(d, "reads.fa")
+        n = write_fasta(reads, fa)
+        out["input"] = {"format": "FASTA (>r\\n<150 bases>\\n)", "reads": n, "bytes": os.path.getsize(fa), "on": "tmpfs"}
+        bins = {os.path.basename(p): p for p in build_host.build()}
+        threads = min(os.cpu_count() or 1, 16)
+        out["kmercount"] = run_cli([bins["spades-kmercount"], "-k", str(k), "-t", str(threads), "-w", d, fa])
+        fk = os.path.join(d, "final_kmers")
+        if os.path.exists(fk):
+            out["kmercount"]["final_kmers_bytes"] = os.path.getsize(fk)
+            os.unlink(fk)
+        gfa = os.path.join(d, "g.gfa")
+        out["gbuilder"] = run_cli([bins["spades-gbuilder"], fa, gfa, "-k", str(k), "-t", str(threads), "--gfa"])
+        if os.path.exists(gfa):
+            out["gbuilder"]["gfa_bytes"] = os.path.getsize(gfa)
+            os.unlink(gfa)
+        os.unlink(fa)
+        # the CPU port end to end on a bounded sample of the same reads: parse (serial, like the reference's master
+        # thread) + count + file write; parse + extension index + unitigs + GFA write
+        from oracle import oracle as O
+        ns = min(args.e2e_cpu_sample_reads, n)
+        sample = ctx.reads_synth(ns, read_len=args.read_len, genome_len=max(args.read_len, ns * args.read_len // 50))
+        sfa = os.path.join(d, "sample.fa")
+        write_fasta(sample, sfa)
+        sample.free()
+        cores = min(os.cpu_count() or 1, 64)
+        t0 = time.perf_counter()
+        blob, offs = O.read_fastx(sfa)
+        t1 = time.perf_counter()
+        st = O.mk_reads_blob(blob, offs)
+        km = O.kmercount(None, k, 16, cores, blob=st)
+        km.tofile(os.path.join(d, "cpu_final_kmers"))
+        t2 = time.perf_counter()
+        x = O.ExtIndex(None, k, max(1, cores // 2 + 1), blob=st)
+        u = x.unitigs()
+        text = u.gfa()[0]
+        with open(os.path.join(d, "cpu.gfa"), "w") as f:
+            f.write(text)
+        t3 = time.perf_counter()
+        out["cpu_port"] = {"kind": "port", "cores": cores, "sample_reads": ns, "parse_s": t1 - t0,
+                           "kmercount_wall_s": t2 - t0, "gbuilder_wall_s": (t1 - t0) + (t3 - t2),
+                           "note": "oracle/bbk_oracle.c end to end on a %d-read sample of the same generator "
+                                   "(serial kseq-style parse, OpenMP count/extension index, sequential unitig walk and "
+                                   "GFA text); scale by reads/sample_reads to compare with the CLI walls" % ns}
+        if "wall_s" in out["kmercount"] and "error" not in out["kmercount"]:
+            out["speedup_vs_cpu_port_scaled"] = {
+                "kmercount": out["cpu_port"]["kmercount_wall_s"] * (n / ns) / out["kmercount"]["wall_s"],
+                "gbuilder": (out["cpu_port"]["gbuilder_wall_s"] * (n / ns) / out["gbuilder"]["wall_s"])
+                if "error" not in out["gbuilder"] else None}
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+def roofline_of(prof, steps, traffic_lookup=None):
+    dom = max(prof, key=lambda f: prof[f]["ms"]) if prof else None
+    if not dom:
+        return None
+    p = prof[dom]
+    ach = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+    traffic, traffic_src = (traffic_lookup(dom) if traffic_lookup else (None, None))
+    return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "launches": p["launches"], "avg_launch_ms": p["ms"] / p["launches"],
+            "algorithmic_bytes_per_launch": p["bytes"] / p["launches"]}
+
+
+def timed_steps(ctx, step, fence, warmup, steps):
+    def drop(x):
+        for y in (x if isinstance(x, (list, tuple)) else [x]):
+            if hasattr(y, "free"):
+                y.free()
+    n_rec = 0
+    for _ in range(warmup):
+        n_rec, keep = step()
+        drop(keep)
+        del keep
+    ctx.profile(True)
+    ctx.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        n_rec, keep = step()
+        drop(keep)
+        del keep
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.profile(False)
+    prof = {f: ctx.profile_get(f) for f in FAMILIES}
+    prof = {f: v for f, v in prof.items() if v["launches"]}
+    return n_rec, dt, prof
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     import torch
     import torch.distributed as dist
     import spades_for_blackbird_amd as B
@@ -111,6 +274,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        return 2
     # BBK_BENCH_FORCE_SHARDED=1: take the N>1 code path (owner partition, RCCL all_to_all, merge, expand) with a
     # single rank -- the only way to exercise it on a one-GPU box
     sharded = world > 1 or os.environ.get("BBK_BENCH_FORCE_SHARDED") == "1"
@@ -119,13 +285,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctx = B.Context(local_rank, stream=torch.cuda.current_stream())
 
     k, L = args.k, args.read_len
-    nw = B.engine.words(k)
     total_reads = args.reads * world
     genome_len = max(L, total_reads * L // 50)
     reads = ctx.reads_synth(args.reads, read_len=L, genome_len=genome_len, seed_genome=42, seed_reads=43 + rank)
@@ -138,6 +302,11 @@ def main():
             s = ctx.count(reads, k, B.BOTH_STRANDS | B.REFERENCE_ORDER)
             ptr, order = s.device_keys()
             assert order == B.ORDER_REFERENCE_BUCKETS16 and (ptr or len(s) == 0)
+            if args.ext_index:
+                n = len(s)
+                s.free()  # configs[2] sizes: the set (115 GB) and the index (60 GB) are not held together
+                x = ctx.extindex(reads, k)
+                return n, x
             return len(s), s
         both = D.sharded_count(ctx, reads, k, both_strands=True, reference_order=True)
         ptr, order = both.device_keys()
@@ -149,25 +318,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def drop(x):
-        if hasattr(x, "free"):
-            x.free()
-
-    for _ in range(args.warmup):
-        n_rec, keep = step()
-        drop(keep)
-        del keep
-    ctx.profile(True)
-    ctx.profile_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_rec, keep = step()
-        drop(keep)
-        del keep
-    fence()
-    dt = time.perf_counter() - t0
-    ctx.profile(False)
+    n_rec, dt, prof = timed_steps(ctx, step, fence, args.warmup, args.steps)
 
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     nn = torch.tensor([n_rec], dtype=torch.int64, device=dev)
@@ -178,44 +329,59 @@ def main():
     distinct_total = int(nn.item())
 
     if rank == 0:
-        prof = {f: ctx.profile_get(f) for f in FAMILIES}
-        prof = {f: v for f, v in prof.items() if v["launches"]}
-        dom = max(prof, key=lambda f: prof[f]["ms"]) if prof else None
-        roof = None
-        if dom:
-            p = prof[dom]
-            ach = p["bytes"] / (p["ms"] * 1e-3) / 1e9
-            traffic, traffic_src = None, None
-            same = (args.reads, L, k, world) == (PMC_WORKLOAD["reads"], PMC_WORKLOAD["read_len"], PMC_WORKLOAD["k"],
-                                                 PMC_WORKLOAD["gpus"])
+        def pmc(dom):
+            same = (args.reads, L, k, world, args.ext_index) == (PMC_WORKLOAD["reads"], PMC_WORKLOAD["read_len"],
+                                                                 PMC_WORKLOAD["k"], PMC_WORKLOAD["gpus"], False)
             if same and os.path.exists(PMC_FILE):
                 fam = json.load(open(PMC_FILE)).get("families", {}).get(dom)
                 if fam:
-                    traffic, traffic_src = fam["hbm_bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 --pmc)"
-            roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                    "launches": p["launches"], "avg_launch_ms": p["ms"] / p["launches"],
-                    "algorithmic_bytes_per_launch": p["bytes"] / p["launches"]}
+                    return fam["hbm_bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 --pmc)"
+            return None, None
+        roof = roofline_of(prof, args.steps, pmc)
         inst_per_gpu = 2 * args.reads * (L - k + 1)
+        if args.ext_index:
+            wl = ("BASELINE.json configs[2]: synthetic %d x %d bp uniform reads, k=%d, k-mer count (both strands, "
+                  "final_kmers order) + DeBruijnExtensionIndex build, 1 MI355X" % (args.reads, L, k)) \
+                if (args.reads, k) == (100_000_000, 55) else \
+                ("synthetic %d x %d bp uniform reads per GPU, k=%d, k-mer count + extension index" % (args.reads, L, k))
+        else:
+            wl = "BASELINE.json configs[1]: synthetic %d x %d bp uniform reads per GPU, k=%d, k-mer count only " \
+                 "(both strands, final_kmers order)" % (args.reads, L, k)
         line = {
-            "metric": "distinct k-mers/sec (k=%d, %d bp synthetic reads, count only)" % (k, L),
+            "metric": "distinct k-mers/sec (k=%d, %d bp synthetic reads, %s)" % (
+                k, L, "count + extension index" if args.ext_index else "count only"),
             "value": distinct_total * 1.0 / (dt_max / args.steps),
             "unit": "distinct k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: synthetic %d x %d bp uniform reads per GPU, k=%d, "
-                                   "k-mer count only (both strands, final_kmers order)" % (args.reads, L, k),
-                       "reads_per_gpu": args.reads, "read_len": L, "k": k, "genome_len": genome_len,
+            "config": {"workload": wl, "reads_per_gpu": args.reads, "read_len": L, "k": k, "genome_len": genome_len,
                        "coverage": 50, "parallelism": "owner-hash shards, %d rank(s)" % world},
             "distinct_kmers": distinct_total,
             "kmer_instances_per_s": inst_per_gpu * world / (dt_max / args.steps),
             "kernel_ms_per_step": {f: v["ms"] / args.steps for f, v in prof.items()},
             "roofline": roof,
         }
-        if world == 1 and not args.no_gfa:
+        big = args.reads > 20_000_000
+        if world == 1 and not args.no_k55 and not big and k != 55:
+            # the 16-byte-key path in front of the driver: the same step at k=55 on the same reads
+            def step55():
+                s = ctx.count(reads, 55, B.BOTH_STRANDS | B.REFERENCE_ORDER)
+                return len(s), s
+            n55, dt55, prof55 = timed_steps(ctx, step55, fence, 1, 2)
+            line["k55"] = {"workload": "the same %d reads, k=55 (16-byte keys), k-mer count only" % args.reads,
+                           "steps": 2, "warmup": 1, "ms_per_step": dt55 / 2 * 1e3, "distinct_kmers": n55,
+                           "value": n55 / (dt55 / 2), "unit": "distinct k-mers/s", "dtype": "u128",
+                           "kernel_ms_per_step": {f: v["ms"] / 2 for f, v in prof55.items()},
+                           "roofline": roofline_of(prof55, 2)}
+        if world == 1 and not args.no_gfa and not big:
             line["gfa_build"] = gfa_build(ctx, reads, k)
+        if world == 1 and not args.no_e2e and not big:
+            try:
+                line["e2e"] = e2e(ctx, reads, args)
+            except Exception as ex:  # the headline must not die with a side measurement
+                line["e2e"] = {"error": repr(ex)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ctx, args, B)
         print(json.dumps(line), flush=True)

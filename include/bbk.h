@@ -66,6 +66,17 @@ int bbk_ctx_profile_get(bbk_ctx *ctx, const char *family, double *ms_total, uint
  * a 64-bit word) and uploads.  Reverse complements are NOT materialised: kernels canonicalise. */
 int bbk_reads_from_ascii(bbk_ctx *ctx, const char *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
                          bbk_reads **out);
+/* Packed reads in HOST memory (what a parser thread of the host produces): read i occupies ceil(len[i]/32) u64
+ * words, the reads follow each other in order, each starting on a 64-bit word (the layout above); bits above a
+ * read's last base must be zero.  n_words must equal the sum of the per-read word counts.  Uploads (fastest from
+ * bbk_host_alloc memory); the word offsets are computed on the device.  The LongestValid rule has already been
+ * applied by the caller (one run of ACGTacgt per record, io/reads/longest_valid_wrapper.hpp:15-52). */
+int bbk_reads_from_packed(bbk_ctx *ctx, const uint64_t *h_words, uint64_t n_words, const uint32_t *h_len,
+                          uint64_t n_reads, bbk_reads **out);
+/* Page-locked host memory for the buffers above (host -> device copies from pageable memory run at a fraction of
+ * the link rate). */
+int bbk_host_alloc(size_t bytes, void **out);
+void bbk_host_free(void *p);
 /* Adopt packed reads already in HBM (not copied, not freed): d_words[u64], d_word_off[u64, n+1]
  * (first word of each read), d_len[u32, n] (bases). */
 int bbk_reads_from_device(bbk_ctx *ctx, const void *d_words, const void *d_word_off, const void *d_len,
@@ -193,6 +204,9 @@ int bbk_unitigs_build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs **out);
  * FillCoverageAndFlankingFromPHM, assembly_graph/graph_support/coverage_filling.hpp:44-62).  After this
  * call the GFA carries DP:f:<KC/(len-k)> and KC:i:<KC> (projects/gbuilder/main.cpp:200-211). */
 int bbk_unitigs_add_coverage(bbk_ctx *ctx, bbk_unitigs *u, const bbk_reads *reads);
+/* same from a table the caller has already counted (streaming input: the reads are gone by now): the ascending
+ * canonical (k+1)-mer set with multiplicities, bbk_count*(k + 1, BBK_CANONICAL | BBK_WITH_COUNTS) */
+int bbk_unitigs_add_coverage_counts(bbk_ctx *ctx, bbk_unitigs *u, const bbk_kmerset *kp1_counts);
 int bbk_unitigs_export_kc(bbk_ctx *ctx, const bbk_unitigs *u, uint64_t *h_kc);
 uint64_t bbk_unitigs_count(const bbk_unitigs *u);
 uint64_t bbk_unitigs_loops(const bbk_unitigs *u);

@@ -1156,3 +1156,143 @@ int orc_unitigs_fasta_write(const orc_unitigs *u, FILE *f) {
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------ */
+/* FASTA/FASTQ(.gz) reader                                             */
+/* ------------------------------------------------------------------ */
+/* Serial restatement of the reference's parser: FastaFastqGzParser::operator>> over the vendored kseq on gzread
+ * (common/io/reads/fasta_fastq_gz_parser.hpp:64-80,113-136; ext/include/kseq/kseq.h:66-76 ks_getc, :88-137
+ * ks_getuntil2, :170-212 kseq_read).  One master thread parses in the reference too (read_processor.hpp:95-111).
+ * Names, comments and qualities are dropped; bases are upper-cased (kseq.h:193-194). */
+#include <zlib.h>
+
+typedef struct {
+    gzFile f;
+    unsigned char buf[16384]; /* KSEQ_INIT bufsize, kseq.h:223 */
+    int begin, end, is_eof;
+} orc_ks;
+
+static int orc_ks_getc(orc_ks *ks) { /* kseq.h:66-76 */
+    if (ks->is_eof && ks->begin >= ks->end) return -1;
+    if (ks->begin >= ks->end) {
+        ks->begin = 0;
+        ks->end = gzread(ks->f, ks->buf, sizeof(ks->buf));
+        if (ks->end <= 0) {
+            ks->end = 0;
+            ks->is_eof = 1;
+            return -1;
+        }
+    }
+    return (int)ks->buf[ks->begin++];
+}
+
+typedef struct {
+    char *s;
+    size_t l, m;
+} orc_str;
+
+static void orc_str_reserve(orc_str *st, size_t need) {
+    if (st->m < need) {
+        st->m = need < 256 ? 256 : need * 2;
+        st->s = (char *)realloc(st->s, st->m);
+    }
+}
+
+/* one line appended to st (st == NULL: skipped); *dret = the delimiter seen ('\n') or 0; returns -1 when nothing
+ * was read and the input is at its end (kseq.h:88-137, delimiter KS_SEP_LINE).  The trailing '\r' rule of
+ * kseq.h:131 looks at the string being appended to, which for a sequence line is the record's sequence so far:
+ * st->s + base. */
+static long orc_ks_getline(orc_ks *ks, orc_str *st, int *dret, size_t base) {
+    int gotany = 0;
+    if (dret) *dret = 0;
+    for (;;) {
+        if (ks->begin >= ks->end) {
+            if (ks->is_eof) break;
+            ks->begin = 0;
+            ks->end = gzread(ks->f, ks->buf, sizeof(ks->buf));
+            if (ks->end <= 0) {
+                ks->end = 0;
+                ks->is_eof = 1;
+                break;
+            }
+        }
+        int i;
+        for (i = ks->begin; i < ks->end; ++i)
+            if (ks->buf[i] == '\n') break;
+        gotany = 1;
+        if (st) {
+            orc_str_reserve(st, st->l + (size_t)(i - ks->begin) + 2);
+            memcpy(st->s + st->l, ks->buf + ks->begin, (size_t)(i - ks->begin));
+            st->l += (size_t)(i - ks->begin);
+        }
+        ks->begin = i + 1;
+        if (i < ks->end) {
+            if (dret) *dret = '\n';
+            break;
+        }
+    }
+    if (!gotany && ks->is_eof && ks->begin >= ks->end) return -1;
+    if (st && st->l - base > 1 && st->s[st->l - 1] == '\r') --st->l;
+    return st ? (long)(st->l - base) : 0;
+}
+
+int orc_fastx_read(const char *path, char **bases, uint64_t **offsets, size_t *n_out) {
+    orc_ks *ks = (orc_ks *)calloc(1, sizeof(orc_ks));
+    ks->f = gzopen(path, "r");
+    if (!ks->f) {
+        free(ks);
+        return -1;
+    }
+    orc_str all = {NULL, 0, 0}, qual = {NULL, 0, 0};
+    size_t n = 0, cap = 1024;
+    uint64_t *off = (uint64_t *)malloc((cap + 1) * sizeof(uint64_t));
+    off[0] = 0;
+    int last_char = 0, c;
+    for (;;) { /* kseq_read, kseq.h:170-212 */
+        if (last_char == 0) { /* jump to the next header line */
+            while ((c = orc_ks_getc(ks)) != -1 && c != '>' && c != '@') {}
+            if (c == -1) break;
+            last_char = c;
+        }
+        if (orc_ks_getline(ks, NULL, &c, 0) < 0) break; /* name: the whole header line (KS_SEP_LINE, kseq.h:182) */
+        const size_t start = all.l;                     /* the record's sequence is the tail of `all` */
+        while ((c = orc_ks_getc(ks)) != -1 && c != '>' && c != '+' && c != '@') {
+            if (c == '\n') continue; /* skip empty lines */
+            orc_str_reserve(&all, all.l + 2);
+            all.s[all.l++] = (char)c;
+            orc_ks_getline(ks, &all, NULL, start); /* rest of the line */
+        }
+        if (c == '>' || c == '@') last_char = c; /* the first header char has been read */
+        else last_char = 0;
+        for (size_t j = start; j < all.l; ++j) /* toupper, kseq.h:193-194 */
+            if (all.s[j] >= 'a' && all.s[j] <= 'z') all.s[j] = (char)(all.s[j] - 32);
+        if (c == '+') {
+            while ((c = orc_ks_getc(ks)) != -1 && c != '\n') {} /* skip the rest of the '+' line */
+            if (c == -1) {                                       /* -2: no quality string */
+                all.l = start;
+                break;
+            }
+            const size_t seq_l = all.l - start;
+            qual.l = 0;
+            while (orc_ks_getline(ks, &qual, NULL, 0) >= 0 && qual.l < seq_l) {}
+            last_char = 0;
+            if (qual.l != seq_l) { /* -2: fasta_fastq_gz_parser.hpp:130-136 treats it as the end of the stream */
+                all.l = start;
+                break;
+            }
+        }
+        if (n == cap) {
+            cap *= 2;
+            off = (uint64_t *)realloc(off, (cap + 1) * sizeof(uint64_t));
+        }
+        off[++n] = all.l;
+    }
+    gzclose(ks->f);
+    free(ks);
+    free(qual.s);
+    if (!all.s) all.s = (char *)calloc(1, 1);
+    *bases = all.s;
+    *offsets = off;
+    *n_out = n;
+    return 0;
+}

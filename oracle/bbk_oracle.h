@@ -69,6 +69,10 @@ typedef struct {
     size_t n;
 } orc_reads;
 
+/* FASTA/FASTQ(.gz) file -> reads (serial, kseq semantics: io/reads/fasta_fastq_gz_parser.hpp:64-80,113-136,
+ * ext/include/kseq/kseq.h:170-212).  *bases and *offsets (n+1 entries) are malloc'ed. */
+int orc_fastx_read(const char *path, char **bases, uint64_t **offsets, size_t *n_out);
+
 /* ---- spades-kmercount (projects/kmercount/main.cpp:64-82,95-120,214-219) ---- */
 /*
  * All k-mers of the normalised reads and of their reverse complements, split

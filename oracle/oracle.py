@@ -75,6 +75,7 @@ def lib():
         L.orc_gfa_write.argtypes = [C.POINTER(_ExtIndex), C.POINTER(_Unitigs), C.c_int, C.c_void_p,
                                     C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.orc_unitigs_fasta_write.argtypes = [C.POINTER(_Unitigs), C.c_void_p]
+        L.orc_fastx_read.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         _LIB = L
     return _LIB
 
@@ -106,6 +107,24 @@ def mk_reads_blob(blob, offsets):
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     st = _Reads(blob, offsets.ctypes.data_as(C.POINTER(C.c_uint64)), len(offsets) - 1)
     return st, (blob, offsets)
+
+
+def read_fastx(path):
+    """FASTA/FASTQ(.gz) file -> (blob bytes, offsets np.uint64[n+1]) with the reference parser's semantics."""
+    b, o, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+    if lib().orc_fastx_read(os.fsencode(path), C.byref(b), C.byref(o), C.byref(n)) != 0:
+        raise IOError("cannot open %s" % path)
+    nn = n.value
+    offs = np.ctypeslib.as_array(C.cast(o, C.POINTER(C.c_uint64)), shape=(nn + 1,)).copy()
+    blob = C.string_at(b, int(offs[nn]))
+    _libc.free(b)
+    _libc.free(o)
+    return blob, offs
+
+
+def read_fastx_list(path):
+    blob, offs = read_fastx(path)
+    return [blob[int(offs[i]):int(offs[i + 1])].decode() for i in range(len(offs) - 1)]
 
 
 def xxh3_64(words_arr):

@@ -8,7 +8,7 @@ HOST = os.path.join(HERE, "host")
 BIN = os.path.join(HERE, "bin")
 PROGRAMS = {"spades-kmercount": "kmercount_main.cpp", "spades-gbuilder": "gbuilder_main.cpp",
             "spades-kmer-estimating": "kmer_estimating_main.cpp", "bbk-fastx-dump": "fastx_dump_main.cpp"}
-HEADERS = ["common.hpp", "dataset.hpp", "fastx.hpp"]
+HEADERS = ["common.hpp", "dataset.hpp", "fastx.hpp", "ingest.hpp"]
 
 
 def build(force=False, verbose=False):
@@ -22,7 +22,7 @@ def build(force=False, verbose=False):
         stale = not os.path.exists(exe) or any(os.path.exists(d) and os.path.getmtime(d) > os.path.getmtime(exe)
                                                for d in deps + [srcp])
         if force or stale:
-            cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", exe, srcp, "-L" + HERE, "-lbbk", "-lz",
+            cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-fopenmp", "-o", exe, srcp, "-L" + HERE, "-lbbk", "-lz",
                    "-Wl,-rpath,$ORIGIN/.."]
             if verbose:
                 print(" ".join(cmd))

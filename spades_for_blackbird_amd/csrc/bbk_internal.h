@@ -189,6 +189,10 @@ inline unsigned words_of(unsigned k) { return (k + 31) >> 5; }
 // the copy of chunk i+1 overlaps the host memcpy of chunk i).
 void d2h_big(bbk_ctx *ctx, void *dst, const void *src, size_t bytes);
 
+// Device -> file: chunks through the pinned staging buffers (copy of chunk i+1 overlaps the positional writes of
+// chunk i, several writers per chunk).  Returns false on a short write.
+bool d2f_big(bbk_ctx *ctx, int fd, uint64_t file_off, const void *src, size_t bytes);
+
 // ---- primitives.hip -------------------------------------------------------------------------
 // One LSD pass selector: kind 0 = bits [shift, shift+bits) of key word `word`;
 // kind 1 = XXH3 bucket (kmer_buckets.hpp:28-33) with nb <= 256 buckets;

@@ -12,6 +12,9 @@
 // canon U rc(canon)  (SURVEY.md 7.4).
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -736,15 +739,23 @@ void bbk_kmerset_free(bbk_kmerset *s) { delete s; }
 int bbk_kmerset_write_final_kmers(bbk_ctx *ctx, const bbk_kmerset *s, const char *path) {
     return guarded([&] {
         BBK_REQUIRE(ctx && s && path, BBK_ERR_ARG, "bbk_kmerset_write_final_kmers: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
         const size_t rec = (size_t)s->W * 8;
-        std::vector<uint64_t> host((s->n * rec) / 8 + 1);
-        const PassDesc pd{1, 0, 0, 8, 16};
-        export_ordered(ctx, s, &pd, host.data(), nullptr, nullptr);
-        FILE *f = fopen(path, "wb");
-        BBK_REQUIRE(f != nullptr, BBK_ERR_IO, "cannot open %s for writing", path);
-        const size_t wr = fwrite(host.data(), 1, s->n * rec, f);
-        const int cl = fclose(f);
-        BBK_REQUIRE(wr == s->n * rec && cl == 0, BBK_ERR_IO, "short write to %s", path);
+        // the records in the final_kmers order on the device (the set itself when it was built in that order),
+        // then device -> file through the pinned staging buffers: no host copy of the whole set
+        DevBuf tmp;
+        const void *src = s->keys.p;
+        if (!s->ref_order && s->n) {
+            tmp.alloc(s->n * rec);
+            const PassDesc pd{1, 0, 0, 8, 16};
+            export_ordered(ctx, s, &pd, tmp.p, nullptr, nullptr);
+            src = tmp.p;
+        }
+        const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        BBK_REQUIRE(fd >= 0, BBK_ERR_IO, "cannot open %s for writing", path);
+        const bool ok = d2f_big(ctx, fd, 0, src, s->n * rec);
+        const int cl = close(fd);
+        BBK_REQUIRE(ok && cl == 0, BBK_ERR_IO, "short write to %s", path);
     });
 }
 

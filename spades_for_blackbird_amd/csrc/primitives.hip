@@ -9,6 +9,8 @@
 // (kmer_index_builder.hpp:281-365).  Integer/HBM-bound work: no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstring>
@@ -116,6 +118,57 @@ void d2h_big(bbk_ctx *ctx, void *dst, const void *src, size_t bytes) {
     }
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
+}
+
+bool d2f_big(bbk_ctx *ctx, int fd, uint64_t file_off, const void *src, size_t bytes) {
+    constexpr size_t kChunk = 32ull << 20;
+    if (bytes == 0) return true;
+    if (!ctx->pinned[0]) {
+        BBK_HIP(hipHostMalloc(&ctx->pinned[0], kChunk, hipHostMallocDefault));
+        BBK_HIP(hipHostMalloc(&ctx->pinned[1], kChunk, hipHostMallocDefault));
+        ctx->pinned_bytes = kChunk;
+    }
+    hipEvent_t ev[2];
+    BBK_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    BBK_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+    auto issue = [&](size_t c) {
+        const size_t off = c * kChunk, sz = std::min(kChunk, bytes - off);
+        (void)hipMemcpyAsync(ctx->pinned[c & 1], (const char *)src + off, sz, hipMemcpyDeviceToHost, ctx->stream);
+        (void)hipEventRecord(ev[c & 1], ctx->stream);
+    };
+    bool ok = true;
+    issue(0);
+    for (size_t c = 0; c < nchunks && ok; ++c) {
+        if (hipEventSynchronize(ev[c & 1]) != hipSuccess) {
+            ok = false;
+            break;
+        }
+        // chunk c + 1 goes to the other buffer, whose writes (chunk c - 1) ended with the last iteration
+        if (c + 1 < nchunks) issue(c + 1);
+        const size_t off = c * kChunk, sz = std::min(kChunk, bytes - off);
+        // several writers per chunk: a single pwrite stream into tmpfs runs at ~1/3 of what the box can do
+        const int T = 4;
+        const size_t part = (sz + T - 1) / T;
+#pragma omp parallel for num_threads(T) schedule(static)
+        for (int t = 0; t < T; ++t) {
+            size_t o = (size_t)t * part;
+            const size_t e = std::min(sz, o + part);
+            while (o < e) {
+                const ssize_t w = pwrite(fd, (const char *)ctx->pinned[c & 1] + o, e - o, (off_t)(file_off + off + o));
+                if (w <= 0) {
+#pragma omp atomic write
+                    ok = false;
+                    break;
+                }
+                o += (size_t)w;
+            }
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    return ok;
 }
 
 constexpr int kThreads = 256;

@@ -99,6 +99,12 @@ __global__ void k_synth_reads(uint64_t n_reads, uint32_t read_len, uint32_t word
     }
 }
 
+// word offset of every read when the reads are stored one after the other, each starting on a 64-bit word
+__global__ void k_len_to_words(const uint32_t *__restrict__ len, uint64_t n, uint64_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ((uint64_t)len[i] + 31u) >> 5;
+}
+
 __global__ void k_len_to_u64(const uint32_t *__restrict__ len, uint64_t n, uint64_t *__restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = len[i];
@@ -272,6 +278,65 @@ int bbk_reads_write_spades_binary(bbk_ctx *ctx, const bbk_reads *r, const char *
         }
         BBK_REQUIRE(ok, BBK_ERR_IO, "short write to %s", sp.c_str());
     });
+}
+
+int bbk_reads_from_packed(bbk_ctx *ctx, const uint64_t *h_words, uint64_t n_words, const uint32_t *h_len,
+                          uint64_t n_reads, bbk_reads **out) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx && out && (n_reads == 0 || h_len) && (n_words == 0 || h_words), BBK_ERR_ARG,
+                    "bbk_reads_from_packed: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        auto rd = new bbk_reads();
+        std::unique_ptr<bbk_reads> guard(rd);
+        rd->ctx = ctx;
+        rd->n = n_reads;
+        rd->n_words = n_words;
+        rd->own_words.alloc((n_words + 1) * sizeof(uint64_t));
+        rd->own_woff.alloc((n_reads + 1) * sizeof(uint64_t));
+        rd->own_len.alloc((n_reads + 1) * sizeof(uint32_t));
+        if (n_words)
+            BBK_HIP(hipMemcpyAsync(rd->own_words.p, h_words, n_words * sizeof(uint64_t), hipMemcpyHostToDevice,
+                                   ctx->stream));
+        if (n_reads)
+            BBK_HIP(hipMemcpyAsync(rd->own_len.p, h_len, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        uint64_t total_words = 0, bases = 0;
+        if (n_reads) {
+            // word offsets and the base count come from the lengths, on the device (two scans)
+            hipLaunchKernelGGL(bbk::k_len_to_words, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, ctx->stream,
+                               rd->own_len.as<uint32_t>(), n_reads, rd->own_woff.as<uint64_t>());
+            bbk::check_launch("k_len_to_words");
+            total_words = bbk::exclusive_scan_u64(ctx, rd->own_woff.as<uint64_t>(), rd->own_woff.as<uint64_t>(), n_reads);
+            bbk::DevBuf bl((n_reads + 1) * sizeof(uint64_t));
+            hipLaunchKernelGGL(bbk::k_len_to_u64, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, ctx->stream,
+                               rd->own_len.as<uint32_t>(), n_reads, bl.as<uint64_t>());
+            bbk::check_launch("k_len_to_u64");
+            bases = bbk::exclusive_scan_u64(ctx, bl.as<uint64_t>(), bl.as<uint64_t>(), n_reads);
+        }
+        BBK_REQUIRE(total_words == n_words, BBK_ERR_ARG,
+                    "bbk_reads_from_packed: the lengths need %llu words, %llu were passed", (unsigned long long)total_words,
+                    (unsigned long long)n_words);
+        BBK_HIP(hipMemcpyAsync(rd->own_woff.as<uint64_t>() + n_reads, &total_words, sizeof(uint64_t),
+                               hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        rd->bases = bases;
+        rd->d_words = rd->own_words.as<uint64_t>();
+        rd->d_woff = rd->own_woff.as<uint64_t>();
+        rd->d_len = rd->own_len.as<uint32_t>();
+        *out = guard.release();
+    });
+}
+
+int bbk_host_alloc(size_t bytes, void **out) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(out, BBK_ERR_ARG, "bbk_host_alloc: NULL argument");
+        void *p = nullptr;
+        BBK_HIP(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault));
+        *out = p;
+    });
+}
+
+void bbk_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int bbk_reads_from_device(bbk_ctx *ctx, const void *d_words, const void *d_word_off, const void *d_len,

@@ -761,38 +761,56 @@ using namespace bbk;
 
 extern "C" {
 
+// KC of every unitig from a table of canonical (k+1)-mer multiplicities
+static void coverage_from_counts(bbk_ctx *ctx, bbk_unitigs *u, const bbk_kmerset *set) {
+    const unsigned k1 = u->k + 1;
+    BBK_REQUIRE(set->k == k1 && set->has_counts && set->sorted && !set->ref_order && (set->flags & BBK_CANONICAL),
+                BBK_ERR_ARG, "coverage needs the ascending canonical %u-mer set with counts "
+                "(BBK_CANONICAL | BBK_WITH_COUNTS at k + 1)", k1);
+    BBK_REQUIRE(set->n < (1ull << 32), BBK_ERR_ARG, "coverage table of %llu (k+1)-mers exceeds the 32-bit lookup index",
+                (unsigned long long)set->n);
+    ensure_host(ctx, u);
+    u->kc.assign(u->n, 0);
+    u->has_cov = true;
+    if (u->n == 0) return;
+    DevBuf pref;
+    const unsigned pbits = build_prefix_index(ctx, set->keys.as<uint64_t>(), set->W, k1, set->n, pref);
+    DevBuf d_bases(u->bases.size() + 16), d_off((u->n + 1) * 8), d_kc(u->n * 8), d_err(16);
+    BBK_HIP(hipMemcpyAsync(d_bases.p, u->bases.data(), u->bases.size(), hipMemcpyHostToDevice, ctx->stream));
+    BBK_HIP(hipMemcpyAsync(d_off.p, u->offsets.data(), (u->n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    BBK_HIP(hipMemsetAsync(d_err.p, 0, 16, ctx->stream));
+    switch (set->W) {
+        case 1: run_kc<1>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
+        case 2: run_kc<2>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
+        case 3: run_kc<3>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
+        case 4: run_kc<4>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
+        default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %u", set->W);
+    }
+    uint32_t herr = 0;
+    d2h(ctx, &herr, d_err.p, 4);
+    BBK_REQUIRE(herr == 0, BBK_ERR_INTERNAL, "coverage: a (k+1)-mer of a unitig is missing from the count table");
+    d2h(ctx, u->kc.data(), d_kc.p, u->n * 8);
+}
+
 int bbk_unitigs_add_coverage(bbk_ctx *ctx, bbk_unitigs *u, const bbk_reads *reads) {
     return guarded([&] {
         BBK_REQUIRE(ctx && u && reads, BBK_ERR_ARG, "bbk_unitigs_add_coverage: NULL argument");
         BBK_HIP(hipSetDevice(ctx->device));
-        ensure_host(ctx, u);
-        const unsigned k1 = u->k + 1;
         // multiplicities of the canonical (k+1)-mers over reads + rc(reads)
         // (CoverageHashMapBuilder::FillCoverageFromStream, utils/ph_map/coverage_hash_map_builder.hpp:15-38)
         bbk_kmerset *set = nullptr;
-        const int rc = bbk_count(ctx, reads, k1, BBK_CANONICAL | BBK_WITH_COUNTS, &set);
+        const int rc = bbk_count(ctx, reads, u->k + 1, BBK_CANONICAL | BBK_WITH_COUNTS, &set);
         if (rc != BBK_OK) throw Error{rc};
         std::unique_ptr<bbk_kmerset, void (*)(bbk_kmerset *)> guard(set, bbk_kmerset_free);
-        u->kc.assign(u->n, 0);
-        u->has_cov = true;
-        if (u->n == 0) return;
-        DevBuf pref;
-        const unsigned pbits = build_prefix_index(ctx, set->keys.as<uint64_t>(), set->W, k1, set->n, pref);
-        DevBuf d_bases(u->bases.size() + 16), d_off((u->n + 1) * 8), d_kc(u->n * 8), d_err(16);
-        BBK_HIP(hipMemcpyAsync(d_bases.p, u->bases.data(), u->bases.size(), hipMemcpyHostToDevice, ctx->stream));
-        BBK_HIP(hipMemcpyAsync(d_off.p, u->offsets.data(), (u->n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        BBK_HIP(hipMemsetAsync(d_err.p, 0, 16, ctx->stream));
-        switch (set->W) {
-            case 1: run_kc<1>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
-            case 2: run_kc<2>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
-            case 3: run_kc<3>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
-            case 4: run_kc<4>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
-            default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %u", set->W);
-        }
-        uint32_t herr = 0;
-        d2h(ctx, &herr, d_err.p, 4);
-        BBK_REQUIRE(herr == 0, BBK_ERR_INTERNAL, "coverage: a (k+1)-mer of a unitig is missing from the count table");
-        d2h(ctx, u->kc.data(), d_kc.p, u->n * 8);
+        coverage_from_counts(ctx, u, set);
+    });
+}
+
+int bbk_unitigs_add_coverage_counts(bbk_ctx *ctx, bbk_unitigs *u, const bbk_kmerset *kp1_counts) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && u && kp1_counts, BBK_ERR_ARG, "bbk_unitigs_add_coverage_counts: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        coverage_from_counts(ctx, u, kp1_counts);
     });
 }
 
@@ -897,48 +915,7 @@ static void write_gfa_device(bbk_ctx *ctx, const bbk_unitigs *u, const char *pat
     }
     const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     BBK_REQUIRE(fd >= 0, BBK_ERR_IO, "cannot open %s for writing", path);
-    constexpr size_t kChunk = 32ull << 20;
-    if (!ctx->pinned[0]) {
-        BBK_HIP(hipHostMalloc(&ctx->pinned[0], kChunk, hipHostMallocDefault));
-        BBK_HIP(hipHostMalloc(&ctx->pinned[1], kChunk, hipHostMallocDefault));
-        ctx->pinned_bytes = kChunk;
-    }
-    hipEvent_t ev[2];
-    BBK_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    BBK_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-    const size_t nchunks = (size_t)((total + kChunk - 1) / kChunk);
-    auto issue = [&](size_t c) {
-        const size_t off = c * kChunk, sz = std::min<size_t>(kChunk, total - off);
-        (void)hipMemcpyAsync(ctx->pinned[c & 1], text.as<char>() + off, sz, hipMemcpyDeviceToHost, ctx->stream);
-        (void)hipEventRecord(ev[c & 1], ctx->stream);
-    };
-    bool ok = true;
-    if (nchunks) issue(0);
-    for (size_t c = 0; c < nchunks && ok; ++c) {
-        BBK_HIP(hipEventSynchronize(ev[c & 1]));
-        if (c + 1 < nchunks) issue(c + 1);
-        const size_t off = c * kChunk, sz = std::min<size_t>(kChunk, total - off);
-        // several writers per chunk: a single pwrite stream into tmpfs runs at ~1/3 of what the box can do
-        const int T = 4;
-        const size_t part = (sz + T - 1) / T;
-#pragma omp parallel for num_threads(T) schedule(static)
-        for (int t = 0; t < T; ++t) {
-            size_t o = (size_t)t * part;
-            const size_t e = std::min(sz, o + part);
-            while (o < e) {
-                const ssize_t w = pwrite(fd, (const char *)ctx->pinned[c & 1] + o, e - o, (off_t)(off + o));
-                if (w <= 0) {
-#pragma omp atomic write
-                    ok = false;
-                    break;
-                }
-                o += (size_t)w;
-            }
-        }
-    }
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipEventDestroy(ev[0]);
-    (void)hipEventDestroy(ev[1]);
+    const bool ok = d2f_big(ctx, fd, 0, text.p, (size_t)total);
     const int cl = close(fd);
     BBK_REQUIRE(ok && cl == 0, BBK_ERR_IO, "short write to %s", path);
 }

@@ -14,7 +14,7 @@ ORDER_SORTED, ORDER_REFERENCE_BUCKETS16 = 0, 1
 SYMBOLS = [
     "bbk_last_error", "bbk_version", "bbk_ctx_create", "bbk_ctx_destroy", "bbk_ctx_set_stream",
     "bbk_ctx_synchronize", "bbk_ctx_profile_enable", "bbk_ctx_profile_reset", "bbk_ctx_profile_get",
-    "bbk_reads_from_ascii", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_from_spades_binary",
+    "bbk_reads_from_ascii", "bbk_reads_from_packed", "bbk_host_alloc", "bbk_host_free", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_from_spades_binary",
     "bbk_reads_write_spades_binary", "bbk_reads_count", "bbk_reads_bases",
     "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
     "bbk_count", "bbk_count_begin", "bbk_count_push_reads", "bbk_count_push_ascii", "bbk_count_finish", "bbk_count_abort",
@@ -23,7 +23,7 @@ SYMBOLS = [
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_clip_tips", "bbk_extindex_free",
-    "bbk_unitigs_build", "bbk_unitigs_add_coverage", "bbk_unitigs_export_kc", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
+    "bbk_unitigs_build", "bbk_unitigs_add_coverage", "bbk_unitigs_add_coverage_counts", "bbk_unitigs_export_kc", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
     "bbk_unitigs_vertices", "bbk_unitigs_links", "bbk_unitigs_export", "bbk_unitigs_export_links",
     "bbk_unitigs_write_gfa", "bbk_unitigs_write_fasta", "bbk_unitigs_write_fastg", "bbk_unitigs_free",
 ]
@@ -60,6 +60,9 @@ def load_library():
     L.bbk_ctx_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(C.c_double)]
     L.bbk_reads_from_ascii.argtypes = [vp, C.c_char_p, vp, u64, C.POINTER(vp)]
     L.bbk_reads_from_device.argtypes = [vp, vp, vp, vp, u64, u64, C.POINTER(vp)]
+    L.bbk_reads_from_packed.argtypes = [vp, vp, u64, vp, u64, C.POINTER(vp)]
+    L.bbk_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.bbk_host_free.argtypes = [vp]
     L.bbk_reads_synth.argtypes = [vp, u64, u32, u64, C.c_double, u64, u64, C.POINTER(vp)]
     L.bbk_reads_from_spades_binary.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     L.bbk_reads_write_spades_binary.argtypes = [vp, vp, C.c_char_p]
@@ -115,6 +118,7 @@ def load_library():
             getattr(L, "bbk_unitigs_" + f).restype = u64
             getattr(L, "bbk_unitigs_" + f).argtypes = [vp]
         L.bbk_unitigs_add_coverage.argtypes = [vp, vp, vp]
+        L.bbk_unitigs_add_coverage_counts.argtypes = [vp, vp, vp]
         L.bbk_unitigs_export_kc.argtypes = [vp, vp, vp]
         L.bbk_unitigs_export.argtypes = [vp, vp, vp, vp]
         L.bbk_unitigs_export_links.argtypes = [vp, vp, vp]
@@ -191,6 +195,14 @@ class Context:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         h = C.c_void_p()
         _check(self._L.bbk_reads_from_ascii(self._h, blob, _ptr(offsets), len(offsets) - 1, C.byref(h)))
+        return Reads(self, h)
+
+    def reads_from_packed(self, words, lens):
+        """Host-packed reads (numpy uint64 words, uint32 lengths; every read starts on a word)."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        h = C.c_void_p()
+        _check(self._L.bbk_reads_from_packed(self._h, _ptr(words), len(words), _ptr(lens), len(lens), C.byref(h)))
         return Reads(self, h)
 
     def reads_from_device(self, d_words, d_word_off, d_len, n_reads, n_words):
@@ -494,6 +506,10 @@ class Unitigs(_Handle):
     def add_coverage(self, reads):
         """gbuilder -c: KC / DP of every condensed edge from the reads."""
         _check(self._L.bbk_unitigs_add_coverage(self.ctx._h, self._h, reads._h))
+
+    def add_coverage_counts(self, kp1_counts):
+        """same from an already counted ascending canonical (k+1)-mer KMerSet with counts"""
+        _check(self._L.bbk_unitigs_add_coverage_counts(self.ctx._h, self._h, kp1_counts._h))
 
     def kc(self):
         a = np.zeros(len(self), dtype=np.uint64)

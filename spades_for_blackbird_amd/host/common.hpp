@@ -3,15 +3,21 @@
 #pragma once
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <omp.h>
 
 #include "../../include/bbk.h"
 #include "dataset.hpp"
 #include "fastx.hpp"
+#include "ingest.hpp"
 
 namespace bbkhost {
 
@@ -48,29 +54,118 @@ inline void check(int rc, const char *what) {
     if (rc != BBK_OK) fatal("%s failed (%d): %s", what, rc, bbk_last_error());
 }
 
-// Reads every file into one host batch (names and qualities dropped) and uploads it.
-inline bbk_reads *load_reads(bbk_ctx *ctx, const std::vector<std::string> &files, uint64_t *n_reads) {
+inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// wall seconds of the phases of a run; printed as one machine-readable line when BBK_PHASES is set (bench.py reads it)
+struct Phases {
+    double ctx = 0, parse = 0, upload = 0, device = 0, finish = 0, write = 0, total = 0, parse_wait = 0;
+    uint64_t blocks = 0, fallback_blocks = 0;
+    void report(const char *tool) const {
+        if (!getenv("BBK_PHASES")) return;
+        printf("BBK_PHASES {\"tool\": \"%s\", \"ctx_s\": %.4f, \"parse_s\": %.4f, \"parse_wait_s\": %.4f, \"upload_s\": %.4f, "
+               "\"device_s\": %.4f, \"finish_s\": %.4f, \"write_s\": %.4f, \"total_s\": %.4f, \"blocks\": %llu, "
+               "\"fallback_blocks\": %llu}\n",
+               tool, ctx, parse, parse_wait, upload, device, finish, write, total, (unsigned long long)blocks,
+               (unsigned long long)fallback_blocks);
+        fflush(stdout);
+    }
+};
+
+inline int default_threads() {
+    int t = omp_get_max_threads();
+    if (t > 16) t = 16;  // the parser saturates memory bandwidth long before that
+    return t < 1 ? 1 : t;
+}
+
+// Streams every file through the parallel block parser (ingest.hpp) and hands each block, uploaded as a bbk_reads, to
+// `push`.  One producer thread parses block i+1 while this thread uploads and pushes block i (the reference overlaps
+// its parsing master thread with the consuming workers the same way, common/io/reads/read_processor.hpp:76-135).
+// block_bytes bounds the host memory: two blocks of text-equivalent packed reads are alive at any time (the -b
+// contract of the reference: bounded buffers, kmer_splitter.hpp:73-109).
+template <class Push>
+inline uint64_t stream_reads(bbk_ctx *ctx, const std::vector<std::string> &files, size_t block_bytes, int threads,
+                             Phases &ph, Push push) {
     // a single SPAdes binary read cache (<prefix>.seq) is taken as is
     if (files.size() == 1 && ends_with(files[0], ".seq")) {
         info("Processing %s (binary read cache)", files[0].c_str());
         bbk_reads *r = nullptr;
         check(bbk_reads_from_spades_binary(ctx, files[0].c_str(), &r), "bbk_reads_from_spades_binary");
-        if (n_reads) *n_reads = bbk_reads_count(r);
-        info("Total %llu reads processed", (unsigned long long)bbk_reads_count(r));
-        return r;
+        const uint64_t n = bbk_reads_count(r);
+        const double t0 = now_s();
+        push(r);
+        ph.device += now_s() - t0;
+        bbk_reads_free(r);
+        info("Total %llu reads processed", (unsigned long long)n);
+        return n;
     }
-    ReadBatch batch;
-    for (const std::string &f : files) {
-        info("Processing %s", f.c_str());
-        FastxReader rd(f);
-        if (!rd.is_open()) fatal("Cannot open %s", f.c_str());
-        while (rd.read(batch, ~0ull, ~0ull) > 0) {}
+    Ingest ing(files, block_bytes, threads);
+    ing.on_file = [](const std::string &f) { info("Processing %s", f.c_str()); };
+    PackedReads slot[2];
+    std::mutex mu;
+    std::condition_variable cv;
+    int ready[2] = {0, 0};  // 0 = free, 1 = filled, 2 = end of input
+    std::string err;
+    double parse_s = 0;
+    std::thread producer([&] {
+        for (int i = 0;; i ^= 1) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return ready[i] == 0; });
+            }
+            const double t0 = now_s();
+            const bool more = ing.next(slot[i], err);
+            parse_s += now_s() - t0;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ready[i] = more ? 1 : 2;
+            }
+            cv.notify_all();
+            if (!more) return;
+        }
+    });
+    uint64_t total = 0;
+    std::string fail;
+    for (int i = 0;; i ^= 1) {
+        const double tw = now_s();
+        int st;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return ready[i] != 0; });
+            st = ready[i];
+        }
+        ph.parse_wait += now_s() - tw;
+        if (st == 2) break;
+        bbk_reads *r = nullptr;
+        if (fail.empty()) {
+            const double t0 = now_s();
+            const int rc = bbk_reads_from_packed(ctx, slot[i].words.data(), slot[i].words.size(), slot[i].len.data(),
+                                                 slot[i].len.size(), &r);
+            ph.upload += now_s() - t0;
+            if (rc != BBK_OK) fail = std::string("bbk_reads_from_packed: ") + bbk_last_error();
+        }
+        total += slot[i].size();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ready[i] = 0;  // the upload has completed: the producer may refill this slot
+        }
+        cv.notify_all();
+        if (r) {
+            const double t0 = now_s();
+            push(r);
+            ph.device += now_s() - t0;
+            bbk_reads_free(r);
+            ++ph.blocks;
+        }
     }
-    info("Total %llu reads processed", (unsigned long long)batch.size());
-    bbk_reads *r = nullptr;
-    check(bbk_reads_from_ascii(ctx, batch.bases.data(), batch.offsets.data(), batch.size(), &r), "bbk_reads_from_ascii");
-    if (n_reads) *n_reads = batch.size();
-    return r;
+    producer.join();
+    ph.parse = parse_s;
+    ph.fallback_blocks = ing.fallback_blocks();
+    if (!err.empty()) fatal("%s", err.c_str());
+    if (!fail.empty()) fatal("%s", fail.c_str());
+    info("Total %llu reads processed", (unsigned long long)total);
+    return total;
 }
 
 inline bool parse_uint(const char *s, unsigned long long *v) {

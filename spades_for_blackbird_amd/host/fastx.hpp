@@ -66,12 +66,20 @@ class FastxReader {
     bool getline_(std::string *dst) {
         int c;
         bool any = false;
+        hit_nl_ = false;
         while ((c = getc_()) != -1) {
             any = true;
-            if (c == '\n') return true;
-            if (dst && c != '\r') dst->push_back((char)c);
+            if (c == '\n') {
+                hit_nl_ = true;
+                return true;
+            }
+            if (dst) dst->push_back((char)c);
         }
         return any;
+    }
+    // kseq.h ks_getuntil2: after a line has been appended, ONE trailing '\r' is dropped when the string is longer than 1
+    static void strip_cr_(std::string &s, size_t start) {
+        if (s.size() - start > 1 && s.back() == '\r') s.pop_back();
     }
     bool next(std::string &out) {
         int c;
@@ -80,15 +88,17 @@ class FastxReader {
             if (c == -1) { eof_ = true; return false; }
             last_char_ = c;
         }
-        getline_(nullptr);  // name + comment
+        if (!getline_(nullptr)) {  // name + comment; a header character that is the last byte: end of file (kseq.h:182)
+            eof_ = true;
+            return false;
+        }
         const size_t start = out.size();
         // sequence lines
         while ((c = getc_()) != -1 && c != '>' && c != '+' && c != '@') {
             if (c == '\n') continue;
             out.push_back((char)c);
-            std::string rest;
-            getline_(&rest);
-            out += rest;
+            getline_(&out);
+            strip_cr_(out, start);
         }
         // every character of a sequence line is kept and upper-cased (kseq.h:190-194)
         for (size_t r = start; r < out.size(); ++r) {
@@ -103,13 +113,18 @@ class FastxReader {
         }
         const size_t seq_len = out.size() - start;
         getline_(nullptr);  // rest of the '+' line
-        size_t qlen = 0;
-        std::string q;
-        while (qlen < seq_len) {
-            q.clear();
-            if (!getline_(&q)) break;
-            qlen += q.size();
+        if (!hit_nl_) {  // the '+' line is the last thing in the file: "no quality string" (kseq.h:205), the stream ends
+            out.resize(start);
+            eof_ = true;
+            return false;
         }
+        // at least one quality line is read, then more until it is as long as the sequence (kseq.h:208)
+        std::string q;
+        do {
+            if (!getline_(&q)) break;
+            strip_cr_(q, 0);
+        } while (q.size() < seq_len);
+        const size_t qlen = q.size();
         last_char_ = 0;
         if (qlen != seq_len) {  // truncated quality string: the reference stops here
             out.resize(start);
@@ -123,7 +138,7 @@ class FastxReader {
     gzFile fp_ = nullptr;
     char buf_[1 << 16];
     int pos_ = 0, len_ = 0;
-    bool eof_in_ = false, eof_ = false;
+    bool eof_in_ = false, eof_ = false, hit_nl_ = false;
     int last_char_ = 0;
 };
 

@@ -3,7 +3,9 @@
 //   one of --unitigs (default) | --fastg | --gfa | --spades            (+ --device <int>, ours)
 // and the same flow (:103-237): reads -> extension index -> unbranching paths + loops ->
 // unitig FASTA or graph -> GFA, with every step behind the C ABI (include/bbk.h).
-// -t/-tmp-dir/-b are accepted for compatibility (no temp files, no per-thread buffers here).
+// -t = parser threads, -b = bytes of input text per block: the reads are streamed block by block through
+// bbk_extindex_begin / push / finish (and, with -c, a (k+1)-mer counter), so host and device memory are bounded as in
+// the reference (binary read chunks + bounded sort buffers); -tmp-dir is accepted (there are no temp files).
 // --spades (binary graph) is a SURVEY 8(f) "next" row and is refused with a clear message.
 #include <cstring>
 #include <string>
@@ -32,6 +34,7 @@ static void usage(const char *argv0) {
 
 int main(int argc, char **argv) {
     unsigned k = 21, device = 0;
+    unsigned long long threads = 0, bufsize = 536870912ull;  // projects/gbuilder/main.cpp:47-52
     bool coverage = false, bad = false;
     enum { UNITIGS, FASTG, GFA, SPADES } mode = UNITIGS;
     int modes_given = 0;
@@ -42,8 +45,8 @@ int main(int argc, char **argv) {
         auto need = [&](unsigned long long *x) { return i + 1 < argc && parse_uint(argv[++i], x); };
         if (a == "-k") { if (need(&v)) k = (unsigned)v; else bad = true; }
         else if (a == "-c") coverage = true;
-        else if (a == "-t") { if (!need(&v)) bad = true; }
-        else if (a == "-b") { if (!need(&v)) bad = true; }
+        else if (a == "-t") { if (need(&v)) threads = v; else bad = true; }
+        else if (a == "-b") { if (need(&v)) bufsize = v; else bad = true; }
         else if (a == "--device") { if (need(&v)) device = (unsigned)v; else bad = true; }
         else if (a == "-tmp-dir") { if (i + 1 < argc) ++i; else bad = true; }
         else if (a == "--unitigs") { mode = UNITIGS; ++modes_given; }
@@ -87,15 +90,28 @@ int main(int argc, char **argv) {
         files.push_back(file);
     }
 
+    Phases ph;
+    const double t_start = now_s();
     bbk_ctx *ctx = nullptr;
     check(bbk_ctx_create((int)device, &ctx), "bbk_ctx_create");
-    uint64_t n_reads = 0;
-    bbk_reads *reads = load_reads(ctx, files, &n_reads);
-    info("Used %llu reads", (unsigned long long)n_reads);
+    ph.ctx = now_s() - t_start;
 
-    // Step 1: build extension index (:169-172)
+    // Step 1: build extension index (:169-172), block by block; with -c the canonical (k+1)-mer multiplicities
+    // (CoverageHashMapBuilder, :200-211) are counted from the same blocks
+    bbk_extbuilder *xb = nullptr;
+    check(bbk_extindex_begin(ctx, k, &xb), "bbk_extindex_begin");
+    bbk_counter *covc = nullptr;
+    const bool want_cov = coverage && mode != UNITIGS;
+    if (want_cov) check(bbk_count_begin(ctx, k + 1, BBK_CANONICAL | BBK_WITH_COUNTS, &covc), "bbk_count_begin");
+    const uint64_t n_reads =
+        stream_reads(ctx, files, (size_t)bufsize, threads ? (int)threads : default_threads(), ph, [&](bbk_reads *r) {
+            check(bbk_extindex_push_reads(xb, r), "bbk_extindex_push_reads");
+            if (covc) check(bbk_count_push_reads(covc, r), "bbk_count_push_reads");
+        });
+    info("Used %llu reads", (unsigned long long)n_reads);
+    double t0 = now_s();
     bbk_extindex *ext = nullptr;
-    check(bbk_extindex_build(ctx, reads, k, &ext), "bbk_extindex_build");
+    check(bbk_extindex_finish(xb, &ext), "bbk_extindex_finish");
     info("K-mer counting done. There are %llu kmers in total.", (unsigned long long)bbk_extindex_size(ext));
     info("Building k-mer extensions from k+1-mers finished.");
 
@@ -107,23 +123,33 @@ int main(int argc, char **argv) {
     info("Collecting perfect loops finished. %llu loops collected", (unsigned long long)bbk_unitigs_loops(u));
 
     if (mode == UNITIGS) {
+        ph.finish = now_s() - t0;
         info("Saving unitigs to %s", outfile.c_str());
+        t0 = now_s();
         check(bbk_unitigs_write_fasta(ctx, u, outfile.c_str()), "bbk_unitigs_write_fasta");
+        ph.write = now_s() - t0;
     } else {
         info("Total %llu edges to create", (unsigned long long)(2 * bbk_unitigs_count(u)));
         info("Total %llu vertices to create", (unsigned long long)bbk_unitigs_vertices(u));
-        if (coverage) {  // Step 4: infer coverage (projects/gbuilder/main.cpp:200-211)
+        if (covc) {  // Step 4: infer coverage (projects/gbuilder/main.cpp:200-211)
             info("Filling coverage index");
-            check(bbk_unitigs_add_coverage(ctx, u, reads), "bbk_unitigs_add_coverage");
+            bbk_kmerset *kp1 = nullptr;
+            check(bbk_count_finish(covc, &kp1), "bbk_count_finish");
+            check(bbk_unitigs_add_coverage_counts(ctx, u, kp1), "bbk_unitigs_add_coverage_counts");
+            bbk_kmerset_free(kp1);
             info("Filling coverage and flanking coverage from PHM");
         }
+        ph.finish = now_s() - t0;
         info("Saving graph to %s", outfile.c_str());
+        t0 = now_s();
         if (mode == GFA) check(bbk_unitigs_write_gfa(ctx, u, outfile.c_str()), "bbk_unitigs_write_gfa");
         else check(bbk_unitigs_write_fastg(ctx, u, outfile.c_str()), "bbk_unitigs_write_fastg");
+        ph.write = now_s() - t0;
     }
     bbk_unitigs_free(u);
     bbk_extindex_free(ext);
-    bbk_reads_free(reads);
+    ph.total = now_s() - t_start;
+    ph.report("spades-gbuilder");
     bbk_ctx_destroy(ctx);
     info("SPAdes standalone graph builder finished");
     return 0;

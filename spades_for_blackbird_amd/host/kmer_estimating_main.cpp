@@ -52,15 +52,17 @@ int main(int argc, char **argv) {
     if (!load_dataset_yaml(dataset, files, err)) fatal("%s", err.c_str());
     bbk_ctx *ctx = nullptr;
     check(bbk_ctx_create((int)device, &ctx), "bbk_ctx_create");
-    uint64_t n_reads = 0;
-    bbk_reads *reads = load_reads(ctx, files, &n_reads);
     info("Estimating kmer cardinality");
+    // strand-independent distinct k-mers: the canonical set; hash-bucket order is enough (no sort); streamed block by block
+    bbk_counter *counter = nullptr;
+    check(bbk_count_begin(ctx, K, BBK_CANONICAL | BBK_UNSORTED, &counter), "bbk_count_begin");
+    Phases ph;
+    stream_reads(ctx, files, 512u << 20, default_threads(), ph,
+                 [&](bbk_reads *r) { check(bbk_count_push_reads(counter, r), "bbk_count_push_reads"); });
     bbk_kmerset *set = nullptr;
-    // strand-independent distinct k-mers: the canonical set; hash-bucket order is enough (no sort)
-    check(bbk_count(ctx, reads, K, BBK_CANONICAL | BBK_UNSORTED, &set), "bbk_count");
+    check(bbk_count_finish(counter, &set), "bbk_count_finish");
     info("Kmer number estimation: %llu", (unsigned long long)bbk_kmerset_size(set));  // :99, exact here
     bbk_kmerset_free(set);
-    bbk_reads_free(reads);
     bbk_ctx_destroy(ctx);
     return 0;
 }

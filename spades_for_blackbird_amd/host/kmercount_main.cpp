@@ -3,7 +3,10 @@
 // the splitter + KMerDiskCounter replaced by the MI355X engine behind the C ABI (include/bbk.h).
 //   -k/--kmer <int=21>  -d/--dataset <yaml>  -t/--threads <int>  -w/--workdir <dir>
 //   -b/--bufsize <bytes>  -h/--help  [input files...]        (+ --device <int>, ours)
-// -t and -b are accepted for compatibility; the device path has no per-thread sort buffers.
+// -t = parser threads (the reference: OpenMP threads of the splitter); -b = bytes of input text per block (the
+// reference: sorting buffer per thread): the input is streamed through bbk_count_begin / push / finish block by block,
+// so host memory is bounded by two blocks and device memory by one block + the distinct set -- the reference's
+// bounded-memory contract (kmer_splitter.hpp:73-109).
 #include <cerrno>
 #include <cstring>
 #include <string>
@@ -36,6 +39,7 @@ static void usage(const char *argv0) {
 
 int main(int argc, char **argv) {
     unsigned K = 21, device = 0;
+    unsigned long long threads = 0, bufsize = 536870912ull;  // projects/kmercount/main.cpp:124-130
     std::string workdir, dataset;
     std::vector<std::string> input;
     bool help = false, bad = false;
@@ -44,8 +48,8 @@ int main(int argc, char **argv) {
         auto need = [&](unsigned long long *v) { return i + 1 < argc && parse_uint(argv[++i], v); };
         unsigned long long v = 0;
         if (a == "-k" || a == "--kmer") { if (need(&v)) K = (unsigned)v; else bad = true; }
-        else if (a == "-t" || a == "--threads") { if (!need(&v)) bad = true; }
-        else if (a == "-b" || a == "--bufsize") { if (!need(&v)) bad = true; }
+        else if (a == "-t" || a == "--threads") { if (need(&v)) threads = v; else bad = true; }
+        else if (a == "-b" || a == "--bufsize") { if (need(&v)) bufsize = v; else bad = true; }
         else if (a == "--device") { if (need(&v)) device = (unsigned)v; else bad = true; }
         else if (a == "-d" || a == "--dataset") { if (i + 1 < argc) dataset = argv[++i]; else bad = true; }
         else if (a == "-w" || a == "--workdir") { if (i + 1 < argc) workdir = argv[++i]; else bad = true; }
@@ -72,20 +76,32 @@ int main(int argc, char **argv) {
         std::string err;
         if (!load_dataset_yaml(dataset, files, err)) fatal("%s", err.c_str());
     }
+    Phases ph;
+    const double t_start = now_s();
     bbk_ctx *ctx = nullptr;
     check(bbk_ctx_create((int)device, &ctx), "bbk_ctx_create");
-    uint64_t n_reads = 0;
-    bbk_reads *reads = load_reads(ctx, files, &n_reads);
+    ph.ctx = now_s() - t_start;
+    // the set is built in the final_kmers order (what CountAll(16, ..., merge=true) leaves on disk, :214-219)
+    bbk_counter *counter = nullptr;
+    check(bbk_count_begin(ctx, K, BBK_BOTH_STRANDS | BBK_REFERENCE_ORDER, &counter), "bbk_count_begin");
+    stream_reads(ctx, files, (size_t)bufsize, threads ? (int)threads : default_threads(), ph, [&](bbk_reads *r) {
+        check(bbk_count_push_reads(counter, r), "bbk_count_push_reads");
+    });
+    double t0 = now_s();
     bbk_kmerset *set = nullptr;
-    check(bbk_count(ctx, reads, K, BBK_BOTH_STRANDS | BBK_REFERENCE_ORDER, &set), "bbk_count");  // built in the final_kmers order
+    check(bbk_count_finish(counter, &set), "bbk_count_finish");
+    ph.finish = now_s() - t0;
     // same line as KMerDiskCounter::Count (common/utils/kmer_mph/kmer_index_builder.hpp:260)
     info("K-mer counting done. There are %llu kmers in total.", (unsigned long long)bbk_kmerset_size(set));
     if (!workdir.empty()) mkdir(workdir.c_str(), 0755);
     const std::string out = (workdir.empty() ? std::string("") : workdir + "/") + "final_kmers";
+    t0 = now_s();
     check(bbk_kmerset_write_final_kmers(ctx, set, out.c_str()), "bbk_kmerset_write_final_kmers");
+    ph.write = now_s() - t0;
     info("K-mer counting done, kmers saved to %s", out.c_str());
     bbk_kmerset_free(set);
-    bbk_reads_free(reads);
+    ph.total = now_s() - t_start;
+    ph.report("spades-kmercount");
     bbk_ctx_destroy(ctx);
     return 0;
 }
