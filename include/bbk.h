@@ -48,6 +48,8 @@ int bbk_ctx_destroy(bbk_ctx *ctx);
 /* Run all kernels of this context on an existing hipStream_t (e.g. torch's current stream). */
 int bbk_ctx_set_stream(bbk_ctx *ctx, void *hip_stream);
 int bbk_ctx_synchronize(bbk_ctx *ctx);
+/* Returns the device memory this context's caching allocator holds (released blocks kept for reuse) to the driver. */
+int bbk_ctx_trim(bbk_ctx *ctx);
 /* Accumulated HIP-event time (ms) and launch count of one named kernel family since the last
  * reset ("extract", "hist", "scan", "scatter", "unique", "expand", "mask", "walk", ...).
  * Timing is only recorded while profiling is enabled (it serialises nothing: events are
@@ -167,6 +169,14 @@ int bbk_kmerset_export_by_owner(bbk_ctx *ctx, const bbk_kmerset *s, unsigned nra
 int bbk_reads_median_filter(bbk_ctx *ctx, const bbk_reads *reads, const bbk_kmerset *counts, unsigned threshold,
                             uint8_t *h_keep, uint64_t *n_kept);
 void bbk_kmerset_free(bbk_kmerset *s);
+/* VERIFY(std::is_sorted(run)) analogue (KMerDiskCounter::MergeKMers, common/utils/kmer_mph/kmer_index_builder.hpp:297),
+ * on the device, for sets too large to download: *n_runs = maximal ascending runs of the stored order (1 for an
+ * ascending set, <= 16 for a set in the final_kmers order), *n_equal = equal neighbours (0 for a distinct set);
+ * h_run_starts (optional, cap entries): record index where each of the first runs begins. */
+int bbk_kmerset_verify_order(bbk_ctx *ctx, const bbk_kmerset *s, uint64_t *n_runs, uint64_t *n_equal,
+                             uint64_t *h_run_starts, unsigned cap);
+/* records [first, first + count) of the stored order (and their multiplicities, if kept) to host memory */
+int bbk_kmerset_get(bbk_ctx *ctx, const bbk_kmerset *s, uint64_t first, uint64_t count, void *h_keys, void *h_counts);
 /* Writes <path> in the final_kmers format (raw little-endian records, no header). */
 int bbk_kmerset_write_final_kmers(bbk_ctx *ctx, const bbk_kmerset *s, const char *path);
 

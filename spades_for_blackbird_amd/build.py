@@ -63,7 +63,67 @@ def build(force=False, verbose=False, extra_flags=None, suffix=""):
     return lib
 
 
+def kernel_resources(objs=None):
+    """Per-kernel scratch and spill figures from the code-object metadata of the built objects
+    (llvm-objdump --offloading + llvm-readelf --notes): [(object, kernel, scratch_bytes, sgpr_spills, vgpr_spills)]."""
+    import re
+    import shutil
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objs = objs or [os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES]
+    out = []
+    for obj in objs:
+        if not os.path.exists(obj):
+            continue
+        d = tempfile.mkdtemp(prefix="bbk_res_")
+        try:
+            local = os.path.join(d, os.path.basename(obj))
+            shutil.copy(obj, local)
+            subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", local], capture_output=True, cwd=d)
+            for f in os.listdir(d):
+                if ARCH not in f:
+                    continue
+                notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", os.path.join(d, f)],
+                                       capture_output=True, text=True).stdout
+                name = None
+                vals = {}
+                for line in notes.splitlines():
+                    m = re.match(r"\s*\.name:\s+(\S+)", line)
+                    if m:
+                        if name:
+                            out.append((os.path.basename(obj), name, vals.get("private_segment_fixed_size", 0),
+                                        vals.get("sgpr_spill_count", 0), vals.get("vgpr_spill_count", 0)))
+                        name, vals = m.group(1), {}
+                        continue
+                    m = re.match(r"\s*\.(private_segment_fixed_size|sgpr_spill_count|vgpr_spill_count):\s+(\d+)", line)
+                    if m and name:
+                        vals[m.group(1)] = int(m.group(2))
+                if name:
+                    out.append((os.path.basename(obj), name, vals.get("private_segment_fixed_size", 0),
+                                vals.get("sgpr_spill_count", 0), vals.get("vgpr_spill_count", 0)))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    # .name also appears for kernel ARGUMENTS in the metadata; kernels are the entries with a mangled / plain symbol
+    return [r for r in out if r[1].startswith("_Z") or r[1].startswith("k_")]
+
+
+def check_resources():
+    """The rule DESIGN.md ties to correct results on this hardware pool: no kernel of the product library may use
+    scratch (private segment) or spill vector registers.  Raises with the offending kernels."""
+    res = kernel_resources()
+    if not res:
+        raise RuntimeError("no kernel metadata found (objects not built?)")
+    bad = [r for r in res if r[2] != 0 or r[4] != 0]
+    if bad:
+        raise RuntimeError("kernels using scratch / spilling VGPRs:\n" +
+                           "\n".join("  %s %s scratch=%d sgpr_spill=%d vgpr_spill=%d" % r for r in bad))
+    return res
+
+
 if __name__ == "__main__":
     extra = [a for a in sys.argv[1:] if a.startswith("-D")]
     suffix = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--suffix=")), "")
     print(build(force="--force" in sys.argv, verbose=True, extra_flags=extra, suffix=suffix))
+    if not suffix:
+        r = check_resources()
+        print("%d kernels: no scratch, no VGPR spills (SGPR spills in %d)" % (len(r), sum(1 for x in r if x[3])))

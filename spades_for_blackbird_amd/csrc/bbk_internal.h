@@ -58,19 +58,20 @@ int guarded(F &&f) {
     }
 }
 
-void *pool_alloc(size_t bytes, size_t *granted);
-void pool_free(void *p, size_t bytes);
-void pool_trim();  // hipFree everything cached
+void *pool_alloc(size_t bytes, size_t *granted, int *device);  // on the current device
+void pool_free(void *p, size_t bytes, int device);
+void pool_trim(int device);  // hipFree what this (device, host thread) has cached
 
 // Owning device buffer.
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    int dev = 0;  // device the block lives on (it returns to that device's free list)
     DevBuf() = default;
     explicit DevBuf(size_t n) { alloc(n); }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) {
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes), dev(o.dev) {
         o.p = nullptr;
         o.bytes = 0;
     }
@@ -79,25 +80,26 @@ struct DevBuf {
             release();
             p = o.p;
             bytes = o.bytes;
+            dev = o.dev;
             o.p = nullptr;
             o.bytes = 0;
         }
         return *this;
     }
     ~DevBuf() { release(); }
-    // Device memory comes from a per-process caching pool (primitives.hip): hipMalloc/hipFree of
+    // Device memory comes from a caching pool (primitives.hip) keyed by (device, host thread): hipMalloc/hipFree of
     // multi-GB buffers cost far more than the kernels that use them, and every step of the path
     // asks for the same sizes again.  All work of a context is issued on one stream, so handing a
-    // released block to the next request is stream-ordered and needs no synchronisation.
+    // released block to the next request of the same context is stream-ordered and needs no synchronisation.
     void alloc(size_t n) {
         release();
         if (n == 0) n = 16;
         size_t got = 0;
-        p = pool_alloc(n, &got);
+        p = pool_alloc(n, &got, &dev);
         bytes = got;
     }
     void release() {
-        if (p) pool_free(p, bytes);
+        if (p) pool_free(p, bytes, dev);
         p = nullptr;
         bytes = 0;
     }

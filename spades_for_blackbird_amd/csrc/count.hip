@@ -107,6 +107,22 @@ __global__ __launch_bounds__(256) void k_expand_rc(const Key<W> *__restrict__ in
     }
 }
 
+// neighbours of the stored order: out[0] += strict descents (key[i+1] < key[i] in word order), out[1] += equal
+// neighbours, out[2..] = the first positions i of a descent (out[2 + 32] of them at most)
+template <int W>
+__global__ __launch_bounds__(256) void k_order_check(const Key<W> *__restrict__ keys, uint64_t n,
+                                                    unsigned long long *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 >= n) return;
+    const Key<W> a = key_load<W>(&keys[i]), b = key_load<W>(&keys[i + 1]);
+    if (key_less_words<W>(b, a)) {
+        const unsigned long long at = atomicAdd(&out[0], 1ull);
+        if (at < 32) out[2 + at] = i;
+    } else if (key_eq<W>(a, b)) {
+        atomicAdd(&out[1], 1ull);
+    }
+}
+
 template <int W>
 static void launch_extract(bbk_ctx *ctx, const bbk_reads *rd, const uint64_t *koff, int k, void *out, uint32_t *vals,
                            uint64_t n_inst) {
@@ -735,6 +751,52 @@ int bbk_kmerset_export_by_owner(bbk_ctx *ctx, const bbk_kmerset *s, unsigned nra
 }
 
 void bbk_kmerset_free(bbk_kmerset *s) { delete s; }
+
+int bbk_kmerset_verify_order(bbk_ctx *ctx, const bbk_kmerset *s, uint64_t *n_runs, uint64_t *n_equal,
+                             uint64_t *h_run_starts, unsigned cap) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && s && n_runs && n_equal, BBK_ERR_ARG, "bbk_kmerset_verify_order: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        *n_runs = s->n ? 1 : 0;
+        *n_equal = 0;
+        if (h_run_starts && cap) h_run_starts[0] = 0;
+        if (s->n < 2) return;
+        DevBuf d(8 * 40);
+        BBK_HIP(hipMemsetAsync(d.p, 0, 8 * 40, ctx->stream));
+        const uint64_t nblk = (s->n + 255) / 256;
+        BBK_REQUIRE(nblk < (1ull << 31), BBK_ERR_ARG, "set too large for one launch");
+        BBK_DISPATCH_W(s->W, hipLaunchKernelGGL((k_order_check<W_>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
+                                                (const Key<W_> *)s->keys.p, s->n,
+                                                (unsigned long long *)d.p));
+        check_launch("k_order_check");
+        unsigned long long h[40];
+        BBK_HIP(hipMemcpyAsync(h, d.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        *n_runs = 1 + h[0];
+        *n_equal = h[1];
+        if (h_run_starts) {
+            const unsigned got = (unsigned)std::min<unsigned long long>(h[0], 32ull);
+            std::sort(h + 2, h + 2 + got);
+            for (unsigned i = 0; i < got && i + 1 < cap; ++i) h_run_starts[i + 1] = h[2 + i] + 1;
+        }
+    });
+}
+
+int bbk_kmerset_get(bbk_ctx *ctx, const bbk_kmerset *s, uint64_t first, uint64_t count, void *h_keys, void *h_counts) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && s && (count == 0 || h_keys), BBK_ERR_ARG, "bbk_kmerset_get: NULL argument");
+        BBK_REQUIRE(first <= s->n && count <= s->n - first, BBK_ERR_ARG, "bbk_kmerset_get: range [%llu, +%llu) outside the set",
+                    (unsigned long long)first, (unsigned long long)count);
+        BBK_HIP(hipSetDevice(ctx->device));
+        if (!count) return;
+        const size_t rec = (size_t)s->W * 8;
+        BBK_HIP(hipMemcpyAsync(h_keys, s->keys.as<char>() + first * rec, count * rec, hipMemcpyDeviceToHost, ctx->stream));
+        if (h_counts && s->has_counts)
+            BBK_HIP(hipMemcpyAsync(h_counts, s->counts.as<uint32_t>() + first, count * 4, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
 
 int bbk_kmerset_write_final_kmers(bbk_ctx *ctx, const bbk_kmerset *s, const char *path) {
     return guarded([&] {

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "bbk_internal.h"
 #include "kmer_ops.h"
@@ -32,30 +33,56 @@ void set_error(const char *fmt, ...) {
 const char *get_error() { return g_err; }
 
 // ---- caching device allocator ---------------------------------------------------------------
+// Free lists are keyed by (device, host thread).  The ABI's contract is one context per GPU per host thread, all of a
+// context's work is issued on its one stream, and every entry point returns with that stream idle or with the
+// released blocks' last use already queued on it -- so inside one key, handing a released block to the next request is
+// stream-ordered.  A block never crosses devices (a foreign-device pointer would fault) nor threads (another
+// context's stream would not be ordered after the releasing one).  bbk_ctx_set_stream drains the old stream first.
 namespace {
+struct PoolKey {
+    int device;
+    std::thread::id thread;
+    bool operator<(const PoolKey &o) const { return device != o.device ? device < o.device : thread < o.thread; }
+};
 struct Pool {
     std::mutex mu;
-    std::multimap<size_t, void *> free_blocks;  // size -> block
-    size_t cached_bytes = 0;
+    std::map<PoolKey, std::multimap<size_t, void *>> free_blocks;  // key -> size -> block
 };
 Pool &pool() {
     static Pool p;
     return p;
 }
 constexpr size_t kPoolGranule = 2ull << 20;  // sizes rounded to 2 MiB: identical steps reuse blocks exactly
+int current_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+}
+// gives every cached block of `device` (all threads) back to the driver; hipFree waits for the device, so blocks
+// whose last use is still queued on another context's stream are safe to free
+void trim_device(int device) {
+    std::lock_guard<std::mutex> g(pool().mu);
+    for (auto &kv : pool().free_blocks) {
+        if (kv.first.device != device) continue;
+        for (auto &b : kv.second) (void)hipFree(b.second);
+        kv.second.clear();
+    }
+}
 }  // namespace
 
-void *pool_alloc(size_t bytes, size_t *granted) {
+void *pool_alloc(size_t bytes, size_t *granted, int *device) {
     const size_t want = bytes <= 4096 ? 4096 : ((bytes + kPoolGranule - 1) / kPoolGranule) * kPoolGranule;
+    const int dev = current_device();
+    *device = dev;
     {
         std::lock_guard<std::mutex> g(pool().mu);
-        auto it = pool().free_blocks.lower_bound(want);
+        auto &fl = pool().free_blocks[PoolKey{dev, std::this_thread::get_id()}];
+        auto it = fl.lower_bound(want);
         // accept a cached block up to 12.5 % larger than asked
-        if (it != pool().free_blocks.end() && it->first <= want + want / 8) {
+        if (it != fl.end() && it->first <= want + want / 8) {
             void *p = it->second;
             *granted = it->first;
-            pool().cached_bytes -= it->first;
-            pool().free_blocks.erase(it);
+            fl.erase(it);
             return p;
         }
     }
@@ -63,7 +90,7 @@ void *pool_alloc(size_t bytes, size_t *granted) {
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        pool_trim();  // give cached blocks back and retry once
+        trim_device(dev);  // give cached blocks back and retry once
         e = hipMalloc(&p, want);
     }
     if (e != hipSuccess) {
@@ -75,17 +102,18 @@ void *pool_alloc(size_t bytes, size_t *granted) {
     return p;
 }
 
-void pool_free(void *p, size_t bytes) {
+void pool_free(void *p, size_t bytes, int device) {
     std::lock_guard<std::mutex> g(pool().mu);
-    pool().free_blocks.emplace(bytes, p);
-    pool().cached_bytes += bytes;
+    pool().free_blocks[PoolKey{device, std::this_thread::get_id()}].emplace(bytes, p);
 }
 
-void pool_trim() {
+// hipFree the blocks cached for this (device, calling thread): what a context being destroyed leaves behind
+void pool_trim(int device) {
     std::lock_guard<std::mutex> g(pool().mu);
-    for (auto &kv : pool().free_blocks) (void)hipFree(kv.second);
-    pool().free_blocks.clear();
-    pool().cached_bytes = 0;
+    auto it = pool().free_blocks.find(PoolKey{device, std::this_thread::get_id()});
+    if (it == pool().free_blocks.end()) return;
+    for (auto &b : it->second) (void)hipFree(b.second);
+    pool().free_blocks.erase(it);
 }
 
 void d2h_big(bbk_ctx *ctx, void *dst, const void *src, size_t bytes) {
@@ -892,7 +920,7 @@ int bbk_ctx_destroy(bbk_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     ctx->resolve_pending();
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    bbk::pool_trim();
+    bbk::pool_trim(ctx->device);
     if (ctx->pinned[0]) (void)hipHostFree(ctx->pinned[0]);
     if (ctx->pinned[1]) (void)hipHostFree(ctx->pinned[1]);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -903,12 +931,22 @@ int bbk_ctx_destroy(bbk_ctx *ctx) {
 int bbk_ctx_set_stream(bbk_ctx *ctx, void *hip_stream) {
     return bbk::guarded([&] {
         BBK_REQUIRE(ctx != nullptr, BBK_ERR_ARG, "bbk_ctx_set_stream: ctx is NULL");
-        if (ctx->own_stream && ctx->stream) {
-            BBK_HIP(hipStreamSynchronize(ctx->stream));
-            BBK_HIP(hipStreamDestroy(ctx->stream));
-        }
+        // drain the old stream: blocks this context has released (their last use queued on it) may be handed out
+        // again for work on the new one
+        BBK_HIP(hipSetDevice(ctx->device));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->own_stream && ctx->stream) BBK_HIP(hipStreamDestroy(ctx->stream));
         ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
         ctx->own_stream = false;
+    });
+}
+
+int bbk_ctx_trim(bbk_ctx *ctx) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx != nullptr, BBK_ERR_ARG, "bbk_ctx_trim: ctx is NULL");
+        BBK_HIP(hipSetDevice(ctx->device));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        bbk::pool_trim(ctx->device);
     });
 }
 

@@ -13,7 +13,7 @@ ORDER_SORTED, ORDER_REFERENCE_BUCKETS16 = 0, 1
 # every symbol include/bbk.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "bbk_last_error", "bbk_version", "bbk_ctx_create", "bbk_ctx_destroy", "bbk_ctx_set_stream",
-    "bbk_ctx_synchronize", "bbk_ctx_profile_enable", "bbk_ctx_profile_reset", "bbk_ctx_profile_get",
+    "bbk_ctx_synchronize", "bbk_ctx_trim", "bbk_kmerset_verify_order", "bbk_kmerset_get", "bbk_ctx_profile_enable", "bbk_ctx_profile_reset", "bbk_ctx_profile_get",
     "bbk_reads_from_ascii", "bbk_reads_from_packed", "bbk_host_alloc", "bbk_host_free", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_from_spades_binary",
     "bbk_reads_write_spades_binary", "bbk_reads_count", "bbk_reads_bases",
     "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
@@ -55,6 +55,9 @@ def load_library():
     L.bbk_ctx_destroy.argtypes = [vp]
     L.bbk_ctx_set_stream.argtypes = [vp, vp]
     L.bbk_ctx_synchronize.argtypes = [vp]
+    L.bbk_ctx_trim.argtypes = [vp]
+    L.bbk_kmerset_verify_order.argtypes = [vp, vp, C.POINTER(u64), C.POINTER(u64), vp, C.c_uint]
+    L.bbk_kmerset_get.argtypes = [vp, vp, u64, u64, vp, vp]
     L.bbk_ctx_profile_enable.argtypes = [vp, i32]
     L.bbk_ctx_profile_reset.argtypes = [vp]
     L.bbk_ctx_profile_get.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(C.c_double)]
@@ -171,6 +174,10 @@ class Context:
 
     def synchronize(self):
         _check(self._L.bbk_ctx_synchronize(self._h))
+
+    def trim(self):
+        """give the allocator's cached device memory back to the driver"""
+        _check(self._L.bbk_ctx_trim(self._h))
 
     def profile(self, on=True):
         _check(self._L.bbk_ctx_profile_enable(self._h, int(on)))
@@ -373,6 +380,19 @@ class KMerSet(_Handle):
         _check(self._L.bbk_kmerset_export_by_owner(self.ctx._h, self._h, nranks, _ptr(dst_keys), _ptr(dst_counts),
                                                    _ptr(counts)))
         return (ret, counts) if ret is not None else counts
+
+    def verify_order(self):
+        """(ascending runs of the stored order, equal neighbours, start index of the first runs) -- on the device"""
+        runs, eq = C.c_uint64(), C.c_uint64()
+        starts = np.zeros(33, dtype=np.uint64)
+        _check(self._L.bbk_kmerset_verify_order(self.ctx._h, self._h, C.byref(runs), C.byref(eq), _ptr(starts), 33))
+        return int(runs.value), int(eq.value), [int(x) for x in starts[:min(int(runs.value), 33)]]
+
+    def get(self, first, count, with_counts=False):
+        keys = np.zeros((count, words(self.k)), dtype=np.uint64)
+        cnt = np.zeros(count, dtype=np.uint32) if with_counts else None
+        _check(self._L.bbk_kmerset_get(self.ctx._h, self._h, first, count, _ptr(keys), _ptr(cnt)))
+        return (keys, cnt) if with_counts else keys
 
     def write_final_kmers(self, path):
         _check(self._L.bbk_kmerset_write_final_kmers(self.ctx._h, self._h, path.encode()))

@@ -1,0 +1,134 @@
+"""GPU: BASELINE.json configs[2] at FULL size -- 100 M x 150 bp synthetic reads, k=55 (16-byte keys), k-mer count +
+DeBruijnExtensionIndex build on one MI355X -- checked through size-independent properties (the oracle would need hours):
+
+  count (both strands, final_kmers order = what spades-kmercount writes):
+    * 9.6 G k-mer positions enter, in 16 hash-range passes; the 5.1 G distinct records come out in <= 16 ascending
+      runs (the XXH3 buckets of KMerSegmentPolicy, kmer_buckets.hpp:28-33) with no two equal neighbours, and the
+      bucket ids at the run boundaries increase;
+    * |both strands| = 2 |canonical| (odd k: no self-reverse-complementary k-mers); multiplicities of the canonical set
+      add up to the number of k-mer positions (nothing lost or counted twice across the range passes);
+    * closure under reverse complement on a sample (the canonical form of a sampled record is in the canonical set);
+  extension index:
+    * ascending canonical k-mers, as many as the canonical count finds; every k-mer has at least one extension bit;
+      the extension bits add up to twice the number of distinct canonical (k+1)-mers.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+R, L, K = 100_000_000, 150, 55
+
+
+def _flip(t):
+    """uint64 order through signed int64 compares: flip the sign bit"""
+    return t ^ (-0x8000000000000000)
+
+
+def _descents(keys, chunk=1 << 27):
+    """positions i with key[i+1] <= key[i] in word order (word 0 most significant, adt/array_vector.hpp:114-123);
+    returns (number of strict descents, number of equal neighbours, positions of the descents)"""
+    import torch
+    n = keys.shape[0]
+    desc, eq, pos = 0, 0, []
+    for a in range(0, n - 1, chunk):
+        b = min(n - 1, a + chunk)
+        x0, x1 = _flip(keys[a:b, 0]), _flip(keys[a:b, 1])
+        y0, y1 = _flip(keys[a + 1:b + 1, 0]), _flip(keys[a + 1:b + 1, 1])
+        less = (y0 < x0) | ((y0 == x0) & (y1 < x1))
+        same = (y0 == x0) & (y1 == x1)
+        desc += int(less.sum().item())
+        eq += int(same.sum().item())
+        if desc <= 64:
+            pos += (torch.nonzero(less).view(-1) + a).cpu().tolist()
+        del x0, x1, y0, y1, less, same
+    return desc, eq, pos
+
+
+def test_configs2_full_size():
+    import torch
+    import spades_for_blackbird_amd as B
+    from oracle import oracle as O
+    from tests.helpers import rc
+    free, total = torch.cuda.mem_get_info()
+    if total < 250e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    ctx = B.Context(0, stream=torch.cuda.current_stream())
+    reads = ctx.reads_synth(R, read_len=L, genome_len=R * L // 50, seed_genome=42, seed_reads=43)
+    n_pos = R * (L - K + 1)
+
+    # ---- canonical set with multiplicities (stage A only: 16 hash-range passes) --------------------------------
+    c = ctx.count(reads, K, B.CANONICAL | B.UNSORTED | B.WITH_COUNTS)
+    n_canon = len(c)
+    assert c.instances == n_pos
+    ck = torch.empty((n_canon, 2), dtype=torch.int64, device="cuda")
+    cc = torch.empty(n_canon, dtype=torch.int32, device="cuda")
+    c.export_by_owner(1, dst_keys=ck, dst_counts=cc)
+    c.free()
+    assert int(cc.sum(dtype=torch.int64).item()) == n_pos          # every k-mer position counted exactly once
+    assert int(cc.min().item()) >= 1
+    del cc, ck
+    torch.cuda.empty_cache()
+    ctx.trim()
+
+    # ---- the product: both strands in the final_kmers order -----------------------------------------------------
+    s = ctx.count(reads, K, B.BOTH_STRANDS | B.REFERENCE_ORDER)
+    n = len(s)
+    assert s.instances == 2 * n_pos
+    assert n == 2 * n_canon
+    ptr, order = s.device_keys()
+    assert order == B.ORDER_REFERENCE_BUCKETS16
+    # checked in place on the device (an 82 GB set is not copied around): VERIFY(is_sorted) analogue
+    runs, eq, starts = s.verify_order()
+    assert eq == 0, "equal neighbours: the set is not distinct"
+    assert runs <= 16, "more than 16 ascending runs"
+    b = [O.bucket(s.get(i, 1)[0], 16) for i in starts]
+    assert b == sorted(b) and len(set(b)) == len(b), b
+    # sample for the closure check
+    step = max(1, n // 300)
+    sample = np.concatenate([s.get(i, 1) for i in range(0, n, step)])
+    s.free()
+    ctx.trim()
+
+    # ---- extension index ------------------------------------------------------------------------------------------
+    x = ctx.extindex(reads, K)
+    nx = len(x)
+    ctx.trim()  # the allocator's cached blocks go back to the driver before torch allocates the export tensors
+    assert nx == n_canon                                            # 150 bp reads: every k-mer has a neighbour
+    xk = torch.empty((nx, 2), dtype=torch.int64, device="cuda")
+    xm = torch.empty(nx, dtype=torch.uint8, device="cuda")
+    x._L.bbk_extindex_export(ctx._h, x._h, B.engine._ptr(xk), B.engine._ptr(xm))
+    x.free()
+    desc, eq, _ = _descents(xk)
+    assert desc == 0 and eq == 0, "extension index keys are not strictly ascending"
+    assert int(xm.min().item()) >= 1
+    pop = torch.tensor([bin(i).count("1") for i in range(16)], dtype=torch.int64, device="cuda")
+    outs = int(pop[(xm & 15).long()].sum().item())
+    ins = int(pop[(xm >> 4).long()].sum().item())
+    # every distinct canonical (k+1)-mer sets exactly two bits (AddOutgoing on its prefix k-mer, AddIncoming on its suffix
+    # k-mer, kmer_extension_index_builder.hpp:44-59; a palindromic 56-mer would set one, probability 4^-28 each)
+    xk_keep = xk
+    c56 = ctx.count(reads, K + 1, B.CANONICAL | B.UNSORTED)
+    n56 = len(c56)
+    c56.free()
+    ctx.trim()
+    assert outs + ins == 2 * n56, (outs, ins, n56)
+    assert n56 > nx
+    # closure under reverse complement: the canonical form of every sampled record of the both-strand set is a key
+    # of the index (binary search on the ascending canonical keys, 128-bit compare on the host)
+    def canon(rec):
+        sq = "".join("ACGT"[(int(rec[i >> 5]) >> (2 * (i & 31))) & 3] for i in range(K))
+        r = rc(sq)
+        return O.kmer_words(sq if O.kmer_is_minimal(sq) else r)
+    for rec in sample:
+        q = tuple(int(v) for v in canon(rec))
+        lo, hi = 0, nx
+        while lo < hi:
+            mid = (lo + hi) // 2
+            m = tuple(int(v) for v in xk[mid].cpu().numpy().view(np.uint64))
+            if m < q:
+                lo = mid + 1
+            else:
+                hi = mid
+        assert lo < nx and tuple(int(v) for v in xk[lo].cpu().numpy().view(np.uint64)) == q
+    ctx.close()

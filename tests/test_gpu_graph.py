@@ -119,8 +119,14 @@ def test_gfa_vs_oracle_synthetic(ctx, k, seed, tmp_path):
     ou = ox.unitigs()
     exp, nv, nl = ou.gfa()
     assert (len(u), u.n_loops, u.n_vertices, u.n_links) == (ou.n, ou.n_loops, nv, nl)
-    if ou.n_loops == 0:
-        assert gfa_canon.canon_md5(txt) == gfa_canon.canon_md5(exp)
+    # loops are compared modulo rotation / reverse complement through the canonical form; the one thing
+    # it cannot normalise is WHICH palindromic (k+1)-mer SplitLoop cuts a self-conjugate circle at (order-dependent
+    # in the reference itself): only then the comparison falls back to segment lengths + counts
+    segs = [l.split("\t")[2] for l in exp.splitlines() if l.startswith("S")]
+    loops = segs[len(segs) - ou.n_loops:] if ou.n_loops else []
+    split = any(s[i:i + k + 1] == rc(s[i:i + k + 1]) for s in loops for i in range(len(s) - k))
+    if not split:
+        assert gfa_canon.canon_text(txt) == gfa_canon.canon_text(exp)
     else:
         gs, gl = gfa_canon.canon(txt)
         es, el = gfa_canon.canon(exp)

@@ -63,3 +63,34 @@ def test_merge_skewed_keys(k, n_rand):
     s2 = ctx.kmerset_from_device(dk, len(allk), k)
     assert np.array_equal(s2.export(B.ORDER_SORTED), exp_k)
     ctx.close()
+
+
+def test_k32_all_T_is_a_legal_key():
+    """k=32: the k-mer T x 32 is the all-ones word, the value the LDS hash table of the 8-byte dedup kernel uses as its
+    empty marker -- that kernel is only selected for 2k < 64, so the key must survive both the unsorted (hash) and the
+    sorted merge of non-canonical input (bbk.h allows any k-mer records here)."""
+    import torch
+    import spades_for_blackbird_amd as B
+    ctx = B.Context(0, stream=torch.cuda.current_stream())
+    rng = np.random.default_rng(5)
+    keys = rng.integers(0, 2**63, size=(200_000, 1), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(200_000, 1), dtype=np.uint64)
+    allT = np.full((3, 1), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+    allk = np.concatenate([keys, allT, keys[:1000], np.zeros((2, 1), dtype=np.uint64)])
+    allk = allk[rng.permutation(len(allk))]
+    dk = torch.from_numpy(allk.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    exp = np.unique(allk[:, 0])
+    s = ctx.kmerset_from_device(dk, len(allk), 32)
+    got = s.export(B.ORDER_SORTED)[:, 0]
+    assert np.array_equal(got, exp) and got[-1] == np.uint64(0xFFFFFFFFFFFFFFFF)
+    u = ctx.kmerset_from_device(dk, len(allk), 32, flags=B.UNSORTED)
+    uk, _ = u.export_by_owner(1)
+    assert np.array_equal(np.sort(uk[:, 0]), exp)
+    # k=31 (the widest key the hash-table kernel takes): T x 31 = 2^62 - 1 must survive too
+    k31 = np.concatenate([keys & np.uint64((1 << 62) - 1), np.full((2, 1), (1 << 62) - 1, dtype=np.uint64)])
+    d31 = torch.from_numpy(k31.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    u31 = ctx.kmerset_from_device(d31, len(k31), 31, flags=B.UNSORTED)
+    g31, _ = u31.export_by_owner(1)
+    assert np.array_equal(np.sort(g31[:, 0]), np.unique(k31[:, 0]))
+    ctx.close()

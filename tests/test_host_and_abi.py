@@ -105,3 +105,13 @@ def test_dataset_yaml(bins, golden_dir, tmp_path):
     r = subprocess.run([exe, "-d", str(y), "-w", str(tmp_path)], capture_output=True, text=True)
     # parsing succeeded iff we get as far as opening the device (no GPU here) or finishing (GPU box)
     assert "ecoli_1K_1.fq.gz" in r.stdout or "bbk_ctx_create" in r.stderr
+
+
+def test_no_kernel_uses_scratch():
+    """DESIGN.md ties wrong results on this hardware pool to kernels that used scratch: the rule "no scratch, no VGPR
+    spills" is enforced on the code-object metadata of every kernel of the built library."""
+    from spades_for_blackbird_amd import build as b
+    b.build()
+    res = b.check_resources()
+    assert len(res) > 150  # all instantiations of all eight translation units are seen
+    assert all(r[2] == 0 and r[4] == 0 for r in res)
