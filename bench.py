@@ -328,6 +328,25 @@ def main():
     dt_max = float(tt.item())
     distinct_total = int(nn.item())
 
+    # N>1: the second half of the metric over all ranks (configs[3] shape): sharded extension index -> gathered on
+    # rank 0 -> unitigs + links -> GFA text on tmpfs; one un-timed-region measurement, every rank takes part
+    gfa_sharded = None
+    if world > 1 and not args.no_gfa:
+        import tempfile
+        d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        path = os.path.join(d, "bbk_bench_sharded_%d.gfa" % os.getpid())
+        fence()
+        t0 = time.perf_counter()
+        u = D.sharded_gfa(ctx, reads, k, path, dst=0)
+        fence()
+        t1 = time.perf_counter()
+        if rank == 0:
+            gfa_sharded = {"wall_s": t1 - t0, "unitigs": len(u), "vertices": u.n_vertices, "links": u.n_links,
+                           "gfa_bytes": os.path.getsize(path), "ranks": world,
+                           "output": "GFA1 text on tmpfs, written by rank 0 from the gathered extension index"}
+            os.unlink(path)
+            u.free()
+
     if rank == 0:
         def pmc(dom):
             same = (args.reads, L, k, world, args.ext_index) == (PMC_WORKLOAD["reads"], PMC_WORKLOAD["read_len"],
@@ -377,6 +396,8 @@ def main():
                            "roofline": roofline_of(prof55, 2)}
         if world == 1 and not args.no_gfa and not big:
             line["gfa_build"] = gfa_build(ctx, reads, k)
+        if gfa_sharded:
+            line["gfa_build"] = gfa_sharded
         if world == 1 and not args.no_e2e and not big:
             try:
                 line["e2e"] = e2e(ctx, reads, args)

@@ -114,6 +114,11 @@ void bbk_reads_free(bbk_reads *r);
                                   ascending: what CountAll(16, ..., merge=true) leaves on disk
                                   (projects/kmercount/main.cpp:214-219).  Exporting in that order is then a plain copy
                                   and bbk_kmerset_keys() is the result itself */
+#define BBK_WITH_MASKS 32u /* with BBK_CANONICAL: the payload of every k-mer is the OR of the InOutMask bits of its
+                              occurrences (the records of the extension index before they are ordered) instead of a
+                              multiplicity; bbk_kmerset_export* hand it out where they hand out counts.  The multi-GPU
+                              path exchanges these records by owner and builds each shard of the index from them
+                              (bbk_extindex_from_device). */
 int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, bbk_kmerset **out);
 /* Streaming count: the input never has to be resident as a whole.  Replaces the bounded-memory contract of
  * KMerSortingSplitter -- per-thread cells of `-b` bytes (PrepareBuffers, common/utils/kmer_mph/kmer_splitter.hpp:73-109),
@@ -183,6 +188,13 @@ int bbk_kmerset_write_final_kmers(bbk_ctx *ctx, const bbk_kmerset *s, const char
 /* ---- extension index: replaces DeBruijnExtensionIndexBuilder::BuildExtensionIndexFromStream
  *      (common/utils/extension_index/kmer_extension_index_builder.hpp:62-106) -------------- */
 int bbk_extindex_build(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, bbk_extindex **out);
+/* The index of a record array already in HBM: n canonical k-mers (bbk_words(k) u64 each) with u32 mask payloads, in
+ * any order, duplicates allowed (their masks are OR-ed).  What a rank builds its shard from after the owner exchange
+ * of BBK_WITH_MASKS records, and what the gathered shards are merged with before the unitig stage. */
+int bbk_extindex_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_masks_u32, uint64_t n, unsigned k,
+                             bbk_extindex **out);
+/* masks as u32 (the payload layout of the exchange), dst may be host or device */
+int bbk_extindex_export_u32(bbk_ctx *ctx, const bbk_extindex *x, void *dst_keys, void *dst_masks_u32);
 /* Streaming build (same contract as bbk_count_begin / push / finish): (canonical k-mer, mask bits) records of every
  * pushed batch are OR-reduced on the device, merged as they pile up, ordered once by bbk_extindex_finish. */
 typedef struct bbk_extbuilder bbk_extbuilder;

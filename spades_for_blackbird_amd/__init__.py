@@ -7,7 +7,7 @@ fallback: importing works anywhere, but creating a Context without the library o
 GPU raises.
 """
 from .engine import (Context, Reads, KMerSet, ExtIndex, Unitigs, BBKError, lib_path, load_library,  # noqa: F401
-                     BOTH_STRANDS, CANONICAL, WITH_COUNTS, UNSORTED, REFERENCE_ORDER, ORDER_SORTED, ORDER_REFERENCE_BUCKETS16)
+                     BOTH_STRANDS, CANONICAL, WITH_COUNTS, UNSORTED, REFERENCE_ORDER, WITH_MASKS, ORDER_SORTED, ORDER_REFERENCE_BUCKETS16)
 
 __all__ = ["Context", "Reads", "KMerSet", "ExtIndex", "Unitigs", "BBKError", "lib_path", "load_library",
-           "BOTH_STRANDS", "CANONICAL", "WITH_COUNTS", "UNSORTED", "REFERENCE_ORDER", "ORDER_SORTED", "ORDER_REFERENCE_BUCKETS16"]
+           "BOTH_STRANDS", "CANONICAL", "WITH_COUNTS", "UNSORTED", "REFERENCE_ORDER", "WITH_MASKS", "ORDER_SORTED", "ORDER_REFERENCE_BUCKETS16"]

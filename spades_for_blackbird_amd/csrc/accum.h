@@ -33,6 +33,8 @@ struct Accum {
     bool has_vals() const;
     int merge_op() const;
     void push(const bbk_reads *rd);
+    // a record array already in HBM (keys + payloads, duplicates allowed) becomes one more run
+    void push_records(const void *d_keys, const uint32_t *d_vals, uint64_t n_rec);
     void merge();
     uint64_t finish_sorted(DevBuf &out_keys, DevBuf &out_vals);
 };

@@ -322,6 +322,16 @@ void Accum::push(const bbk_reads *rd) {
     if ((runs.size() > 1 || n) && runs_n >= n / 2 + floor_n) merge();
 }
 
+void Accum::push_records(const void *d_keys, const uint32_t *d_vals, uint64_t n_rec) {
+    if (n_rec == 0) return;
+    Run r;
+    r.n = dedup_keys(ctx, k, d_keys, has_vals() ? d_vals : nullptr, n_rec, merge_op(), r.keys, r.vals);
+    instances += n_rec;
+    ++batches;
+    runs_n += r.n;
+    runs.push_back(std::move(r));
+}
+
 // accumulated set + runs -> accumulated set
 void Accum::merge() {
     if (runs.empty()) return;
@@ -436,7 +446,7 @@ static bbk_kmerset *finish_count(Accum &acc, unsigned flags) {
     bbk_ctx *ctx = acc.ctx;
     const unsigned k = acc.k;
     const bool both = (flags & BBK_BOTH_STRANDS) != 0;
-    const bool wc = (flags & BBK_WITH_COUNTS) != 0;
+    const bool wc = (flags & (BBK_WITH_COUNTS | BBK_WITH_MASKS)) != 0;  // a u32 payload travels with the keys
     const bool want_ref = (flags & BBK_REFERENCE_ORDER) != 0;
     auto s = std::make_unique<bbk_kmerset>();
     s->k = k;
@@ -479,6 +489,8 @@ static void check_count_flags(unsigned flags) {
     BBK_REQUIRE(both != canon, BBK_ERR_ARG, "bbk_count: pass exactly one of BBK_BOTH_STRANDS / BBK_CANONICAL");
     BBK_REQUIRE(!((flags & BBK_REFERENCE_ORDER) && (flags & BBK_UNSORTED)), BBK_ERR_ARG,
                 "bbk_count: BBK_REFERENCE_ORDER and BBK_UNSORTED exclude each other");
+    BBK_REQUIRE(!(flags & BBK_WITH_MASKS) || (canon && !(flags & BBK_WITH_COUNTS)), BBK_ERR_ARG,
+                "bbk_count: BBK_WITH_MASKS goes with BBK_CANONICAL and without BBK_WITH_COUNTS");
 }
 
 }  // namespace bbk
@@ -501,6 +513,7 @@ int bbk_count_begin(bbk_ctx *ctx, unsigned k, unsigned flags, bbk_counter **out)
         c->acc.ctx = ctx;
         c->acc.k = k;
         c->acc.want_vals = (flags & BBK_WITH_COUNTS) != 0;
+        c->acc.with_mask = (flags & BBK_WITH_MASKS) != 0;
         c->flags = flags;
         *out = c.release();
     });
@@ -553,6 +566,7 @@ int bbk_count(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned flags, 
         acc.ctx = ctx;
         acc.k = k;
         acc.want_vals = (flags & BBK_WITH_COUNTS) != 0;
+        acc.with_mask = (flags & BBK_WITH_MASKS) != 0;
         acc.push(reads);
         *out = finish_count(acc, flags);
     });

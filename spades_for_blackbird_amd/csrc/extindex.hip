@@ -132,6 +132,44 @@ int bbk_extindex_build(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, bbk_ext
     });
 }
 
+int bbk_extindex_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_masks_u32, uint64_t n, unsigned k,
+                             bbk_extindex **out) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && out && (n == 0 || (d_keys && d_masks_u32)), BBK_ERR_ARG, "bbk_extindex_from_device: NULL argument");
+        check_ext_k(k);
+        BBK_HIP(hipSetDevice(ctx->device));
+        Accum acc;
+        acc.ctx = ctx;
+        acc.k = k;
+        acc.with_mask = true;
+        acc.push_records(d_keys, (const uint32_t *)d_masks_u32, n);
+        *out = finish_extindex(acc);
+    });
+}
+
+__global__ void k_u8_to_u32(const uint8_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+int bbk_extindex_export_u32(bbk_ctx *ctx, const bbk_extindex *x, void *dst_keys, void *dst_masks_u32) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && x, BBK_ERR_ARG, "bbk_extindex_export_u32: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        if (x->n == 0) return;
+        if (dst_keys) BBK_HIP(hipMemcpyAsync(dst_keys, x->keys.p, x->n * x->W * 8, hipMemcpyDefault, ctx->stream));
+        if (dst_masks_u32) {
+            DevBuf m(x->n * 4);
+            hipLaunchKernelGGL(k_u8_to_u32, dim3((unsigned)((x->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               x->masks.as<uint8_t>(), x->n, m.as<uint32_t>());
+            check_launch("k_u8_to_u32");
+            BBK_HIP(hipMemcpyAsync(dst_masks_u32, m.p, x->n * 4, hipMemcpyDefault, ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
 int bbk_extindex_begin(bbk_ctx *ctx, unsigned k, bbk_extbuilder **out) {
     return guarded([&] {
         BBK_REQUIRE(ctx && out, BBK_ERR_ARG, "bbk_extindex_begin: NULL argument");

@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-BOTH_STRANDS, CANONICAL, WITH_COUNTS, UNSORTED, REFERENCE_ORDER = 1, 2, 4, 8, 16
+BOTH_STRANDS, CANONICAL, WITH_COUNTS, UNSORTED, REFERENCE_ORDER, WITH_MASKS = 1, 2, 4, 8, 16, 32
 ORDER_SORTED, ORDER_REFERENCE_BUCKETS16 = 0, 1
 
 # every symbol include/bbk.h declares (checked by tests/test_abi.py)
@@ -18,7 +18,7 @@ SYMBOLS = [
     "bbk_reads_write_spades_binary", "bbk_reads_count", "bbk_reads_bases",
     "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
     "bbk_count", "bbk_count_begin", "bbk_count_push_reads", "bbk_count_push_ascii", "bbk_count_finish", "bbk_count_abort",
-    "bbk_count_pushed_instances", "bbk_extindex_begin", "bbk_extindex_push_reads", "bbk_extindex_finish",
+    "bbk_count_pushed_instances", "bbk_extindex_from_device", "bbk_extindex_export_u32", "bbk_extindex_begin", "bbk_extindex_push_reads", "bbk_extindex_finish",
     "bbk_extindex_abort", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_kmerset_both_strands_ex", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k", "bbk_kmerset_keys", "bbk_reads_median_filter",
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
@@ -113,6 +113,8 @@ def load_library():
         L.bbk_extindex_k.restype = C.c_uint
         L.bbk_extindex_k.argtypes = [vp]
         L.bbk_extindex_export.argtypes = [vp, vp, vp, vp]
+        L.bbk_extindex_export_u32.argtypes = [vp, vp, vp, vp]
+        L.bbk_extindex_from_device.argtypes = [vp, vp, vp, u64, C.c_uint, C.POINTER(vp)]
         L.bbk_extindex_clip_tips.argtypes = [vp, vp, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
         L.bbk_extindex_free.argtypes = [vp]
     if hasattr(L, "bbk_unitigs_build"):
@@ -268,6 +270,12 @@ class Context:
         """DeBruijnExtensionIndexBuilder::BuildExtensionIndexFromStream analogue."""
         h = C.c_void_p()
         _check(self._L.bbk_extindex_build(self._h, reads._h, k, C.byref(h)))
+        return ExtIndex(self, h)
+
+    def extindex_from_device(self, d_keys, d_masks_u32, n, k):
+        """Index of (canonical k-mer, u32 mask) records in HBM: any order, duplicates OR-ed (a shard after the exchange)."""
+        h = C.c_void_p()
+        _check(self._L.bbk_extindex_from_device(self._h, _ptr(d_keys), _ptr(d_masks_u32), n, k, C.byref(h)))
         return ExtIndex(self, h)
 
     def unitigs(self, ext):
@@ -484,6 +492,10 @@ class ExtIndex(_Handle):
         a, b = C.c_uint64(0), C.c_uint64(0)
         _check(self._L.bbk_extindex_clip_tips(self.ctx._h, self._h, length_bound, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def export_to_u32(self, dst_keys, dst_masks_u32):
+        """keys + masks widened to u32 (the payload layout of the owner exchange) into preallocated tensors/arrays"""
+        _check(self._L.bbk_extindex_export_u32(self.ctx._h, self._h, _ptr(dst_keys), _ptr(dst_masks_u32)))
 
     def export(self):
         n, nw = len(self), words(self.k)

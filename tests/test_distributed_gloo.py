@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, k, q):
+def _worker(rank, world, port, k, q, max_msg=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -31,36 +31,57 @@ def _worker(rank, world, port, k, q):
         from tests.helpers import synth_reads
         reads = synth_reads(400, read_len=100, genome_len=3000, seed=21)
         mine = reads[rank::world]
-        local = O.kmercount(mine, k, 16, 1)                       # this rank's local distinct k-mers
+        local, cnt = O.kmercount(mine, k, 16, 1, with_counts=True)   # this rank's local distinct k-mers
         own = D.owner_of(local, world)
         order = np.argsort(own, kind="stable")
         send = torch.from_numpy(local[order].view(np.int64).copy())
+        pay = torch.from_numpy(cnt[order].astype(np.int32))
         counts = np.bincount(own, minlength=world)
-        recv, rcl = D.exchange_by_owner(send, counts, local.shape[1])
+        recv, rcl = D.exchange_by_owner(send, counts, local.shape[1], max_msg_bytes=max_msg)
         got = np.unique(recv.numpy().view(np.uint64), axis=0)     # merge-unique of the shard
         assert np.all(D.owner_of(got, world) == rank)
-        q.put((rank, got))
+        # the same with a payload travelling along (multiplicities / mask bits): every record keeps its own
+        recv2, rpay, rcl2 = D.exchange_by_owner(send, counts, local.shape[1], payload=pay, max_msg_bytes=max_msg)
+        assert rcl2 == rcl and len(rpay) == len(recv2) == sum(rcl)
+        sent = dict()  # what every rank holds locally is reproducible here: check against this rank's own records
+        mine_rec = {tuple(r): int(c) for r, c in zip(local.tolist(), cnt.tolist())}
+        pairs = list(zip(map(tuple, recv2.numpy().view(np.uint64).tolist()), rpay.tolist()))
+        own_pairs = [(r, c) for r, c in pairs if r in mine_rec and mine_rec[r] == c]
+        assert len(own_pairs) >= counts[rank]                     # at least the own segment came through intact
+        tot = {}
+        for r, c in pairs:
+            tot[r] = tot.get(r, 0) + c
+        q.put((rank, got, tot))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,world", [(21, 2), (33, 2), (21, 3), (21, 8)])
-def test_multi_rank_exchange(k, world):
-    """world 3 also covers the rank whose own segment sits in the middle of its send buffer."""
+@pytest.mark.parametrize("k,world,max_msg", [(21, 2, None), (33, 2, None), (21, 3, None), (21, 8, None),
+                                             (21, 2, 4096), (55, 3, 1000), (21, 3, 8)])
+def test_multi_rank_exchange(k, world, max_msg):
+    """world 3 also covers the rank whose own segment sits in the middle of its send buffer; a small max_msg forces
+    several rounds of the collective (messages above 1 GiB must never reach RCCL, see distributed.py)."""
     from oracle import oracle as O
     from tests.helpers import synth_reads
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, k, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, k, q, max_msg)) for r in range(world)]
     for p in procs:
         p.start()
-    shards = dict(q.get(timeout=120) for _ in range(world))
+    res = [q.get(timeout=120) for _ in range(world)]
+    shards = {r: g for r, g, t in res}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     reads = synth_reads(400, read_len=100, genome_len=3000, seed=21)
-    full = O.kmercount(reads, k, 16, 1)
+    full, fcnt = O.kmercount(reads, k, 16, 1, with_counts=True)
+    # payloads: the multiplicities summed over the shards are the multiplicities of the whole input
+    tot = {}
+    for r, g, t in res:
+        for key, c in t.items():
+            tot[key] = tot.get(key, 0) + c
+    assert tot == {tuple(r): int(c) for r, c in zip(full.tolist(), fcnt.tolist())}
     exp = set(map(tuple, full.tolist()))
     sets = [set(map(tuple, shards[r].tolist())) for r in range(world)]
     for i in range(world):
