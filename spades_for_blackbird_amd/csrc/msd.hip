@@ -108,7 +108,39 @@ struct PartLevel {
     uint32_t *spill_vals;  // payloads alongside (records with a payload)
     uint32_t *spill_count; // records appended (may run past spill_cap: the host checks)
     uint32_t spill_cap;
+    // narrow stage A (8-byte keys, 2k - 32 = narrow_hb in [1, 10]): 4-byte records between the levels, see "narrow" below
+    int narrow_hb;
 };
+
+// ---- narrow records (stage A, 17 <= k <= 21) ---------------------------------------------------------------
+// A k-mer of 2k <= 42 bits is (hi: 2k - 32 bits, lo: 32 bits = its first 16 bases).  Level 1 sends it to segment
+//   bin1 = hi ^ G(lo)            (G: hb bits of a multiplicative mix of lo; for hb < 10 the bin is filled up to 10 bits
+//                                 with further hash bits of lo)
+// and stores ONLY lo: inside a segment lo determines hi (= bin1 ^ G(lo)), so 4-byte records are exact -- equal lo <=>
+// equal k-mer.  Level 2 and the in-LDS dedup work on lo alone (their bins / slots are other bits of the same mix),
+// the dedup kernel rebuilds the 8-byte key from (segment, lo) when it writes the distinct records.  The canonical
+// stream -- 1.3 G records at BASELINE configs[1], 8.3x the distinct set -- travels as 4 bytes per record instead of 8
+// through its three passes (level-1 write, level-2 read + write, dedup read).
+constexpr int kNwBins1 = 1024;
+__device__ inline uint32_t nw_mix(uint32_t lo) {
+    uint32_t t = lo * 0x9E3779B1u;
+    t ^= t >> 15;
+    t *= 0x85EBCA6Bu;
+    t ^= t >> 13;
+    return t;
+}
+__device__ inline uint32_t nw_g(uint32_t t, int hb) { return ((t * 0xC2B2AE35u) >> 22) & ((1u << hb) - 1u); }
+__device__ inline uint32_t nw_slot(uint32_t t) { return (t * 0x27D4EB2Fu) >> 19; }  // 13 bits for the LDS table
+__device__ inline uint32_t nw_bin1(uint32_t hi, uint32_t t, int hb) {
+    const uint32_t hp = hi ^ nw_g(t, hb);
+    return hb >= 10 ? hp : (hp << (10 - hb)) | (t >> (22 + hb));
+}
+// prefix for level 2: the bits of the mix that level 1 has not used (top-aligned)
+__device__ inline uint32_t nw_p2(uint32_t t, int hb) { return hb >= 10 ? t : t << (10 - hb); }
+__device__ inline uint64_t nw_key(uint32_t bin1, uint32_t lo, int hb) {
+    const uint32_t hi = (bin1 >> (10 - hb)) ^ nw_g(nw_mix(lo), hb);
+    return ((uint64_t)hi << 32) | lo;
+}
 
 // applies the range selection: false = the record belongs to another pass; p loses the selection bits
 __device__ inline bool select_prefix(uint32_t &p, const PartLevel &L) {
@@ -683,11 +715,17 @@ __device__ __forceinline__ void chunk_records(const ChunkWords C, uint32_t k_, c
                 if (p >= 1) m |= 1u << (minimal ? 4u + prevc : 3u - prevc);
                 vals[i] = m;
             }
-            uint32_t pfx = part_hash32<W>(keys[i]);
-            if (select_prefix(pfx, L)) {
-                const uint32_t b = L.b1 == 0 ? 0u : (pfx >> (32 - L.b1));
+            if (W == 1 && L.narrow_hb) {  // narrow stage A: bin from (hi, mix(lo)); rank < 16384
+                const uint32_t b = nw_bin1((uint32_t)(keys[i].w[0] >> 32), nw_mix((uint32_t)keys[i].w[0]), L.narrow_hb);
                 const uint32_t rank = atomicAdd(&lhist[b], 1u);
                 binrank[i] = (b << 16) | rank;
+            } else {
+                uint32_t pfx = part_hash32<W>(keys[i]);
+                if (select_prefix(pfx, L)) {
+                    const uint32_t b = L.b1 == 0 ? 0u : (pfx >> (32 - L.b1));
+                    const uint32_t rank = atomicAdd(&lhist[b], 1u);
+                    binrank[i] = (b << 16) | rank;
+                }
             }
         }
     }
@@ -1751,6 +1789,480 @@ __global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, uint64_t n, 
 }
 
 // ------------------------------------------------------------------------------------------
+// narrow stage A kernels (4-byte records, see "narrow records" above): level 1 from reads, level 2, dedup
+// ------------------------------------------------------------------------------------------
+constexpr int kNwThreads = 1024;
+constexpr int kNwRounds = 2;      // chunks of 8 k-mer positions per lane (the second round is 7/8 populated)
+constexpr int kNwChunks = 1920;   // chunks of a level-1 tile: 15360 records = 60 KB staged, runs of ~15 per bin;
+constexpr int kNwTile = kNwChunks * 8;  // with the tables 77 KB of LDS: two workgroups per CU
+
+template <bool FAST, bool HAS_VAL>
+__device__ __forceinline__ void nw_extract(const ReadSrc &S, const PartLevel &L, uint32_t k_, uint32_t tid, uint32_t nch,
+                                           uint64_t c0, uint32_t r0, uint32_t nr, const int32_t *s_rel,
+                                           const int32_t *s_wrel, const uint32_t *s_len, const uint64_t *s_words,
+                                           uint32_t *lhist, uint32_t (&lo)[8 * kNwRounds], uint32_t (&vals)[8 * kNwRounds],
+                                           uint32_t (&binrank)[8 * kNwRounds]) {
+    constexpr int CH = 8;
+#pragma unroll
+    for (int r = 0; r < kNwRounds; ++r) {
+        const uint32_t ci = (uint32_t)r * kNwThreads + tid;  // chunk of this lane inside the tile
+        Key<1> kk[CH];
+        uint32_t vv[CH], br[CH];
+        if (FAST) {
+            ChunkWords C{s_words, 0, 0, 0};
+            if (ci < nch) {
+                const uint32_t ri = read_of(s_rel, nr, (int32_t)ci);
+                C.p = (uint32_t)((int32_t)ci - s_rel[ri]) * CH;
+                C.len = s_len[ri];
+                const uint32_t nk = C.len - k_ + 1u;
+                C.cnt = nk - C.p < (uint32_t)CH ? nk - C.p : (uint32_t)CH;
+                C.rw = s_words + s_wrel[ri];
+            }
+            chunk_records<1, CH, HAS_VAL>(C, k_, L, (uint32_t)kNwBins1, lhist, kk, vv, br);
+        } else {
+            ChunkWords C{S.words, 0, 0, 0};
+            if (ci < nch) {
+                const uint64_t c = c0 + ci;
+                uint64_t lo_r = r0, hi_r = (uint64_t)r0 + nr;  // largest r with coff[r] <= c
+                while (hi_r - lo_r > 1) {
+                    const uint64_t mid = (lo_r + hi_r) >> 1;
+                    if (S.coff[mid] <= c) lo_r = mid;
+                    else hi_r = mid;
+                }
+                C.p = (uint32_t)(c - S.coff[lo_r]) * CH;
+                C.len = S.len[lo_r];
+                const uint32_t nk = C.len - k_ + 1u;
+                C.cnt = nk - C.p < (uint32_t)CH ? nk - C.p : (uint32_t)CH;
+                C.rw = S.words + S.woff[lo_r];
+            }
+            chunk_records<1, CH, HAS_VAL>(C, k_, L, (uint32_t)kNwBins1, lhist, kk, vv, br);
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            lo[r * CH + i] = (uint32_t)kk[i].w[0];
+            vals[r * CH + i] = vv[i];
+            binrank[r * CH + i] = br[i];
+        }
+    }
+}
+
+// Level 1: fused extraction (the chunk code of k_part_reads) + partition into 1024 segments.  The bin of a staged
+// record cannot be recomputed from lo alone, and a per-record side array would cost as much LDS as the stage itself:
+// the staged order is bin-major, so one bit per position marks where a non-empty bin starts and
+// bin(pos) = nz[#marks at or before pos - 1] (a 64-position word of marks is exactly what a wave handles per step).
+template <bool HAS_VAL>
+__global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, PartLevel L, uint32_t *__restrict__ cursor,
+                                                                 uint32_t *__restrict__ out, uint32_t *__restrict__ vout) {
+    constexpr int NT = kNwThreads, CH = 8, MAXB = kNwBins1, ITEMS = CH * kNwRounds;
+    constexpr int MW = kNwTile / 64;  // 64-bit mark words
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *lstart = lhist + MAXB;
+    uint32_t *goff = lstart + MAXB;
+    uint32_t *scan_tmp = goff + MAXB;                                       // 64 entries
+    unsigned long long *mark = reinterpret_cast<unsigned long long *>(scan_tmp + 64);  // MW words
+    uint16_t *mbase = reinterpret_cast<uint16_t *>(mark + MW);              // marks before every word
+    uint16_t *nz = mbase + MW;                                              // r-th non-empty bin
+    unsigned char *U = reinterpret_cast<unsigned char *>(nz + MAXB);
+    int32_t *s_rel = reinterpret_cast<int32_t *>(U);
+    int32_t *s_wrel = s_rel + (kRdSlots + 2);
+    uint32_t *s_len = reinterpret_cast<uint32_t *>(s_wrel + (kRdSlots + 2));
+    uint64_t *s_words = reinterpret_cast<uint64_t *>(s_len + (kRdSlots + 2));
+    uint32_t *stage = reinterpret_cast<uint32_t *>(U);
+    uint8_t *vstage = reinterpret_cast<uint8_t *>(stage + kNwTile);  // payloads of this path are 8 mask bits
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t k_ = (uint32_t)S.k;
+    const int hb = L.narrow_hb;
+    lhist[tid] = 0;  // NT == MAXB
+    if (tid < MW) mark[tid] = 0ull;
+
+    const uint32_t tile = blockIdx.x;
+    const uint64_t c0 = (uint64_t)tile * kNwChunks;
+    const uint64_t left = S.n_chunks - c0;
+    const uint32_t nch = left < (uint64_t)kNwChunks ? (uint32_t)left : (uint32_t)kNwChunks;
+    const RdTile T = S.tiles[tile];
+    const uint32_t r0 = T.r0, nr = T.nr;
+    const uint64_t wbase = T.wbase;
+    bool fast = T.wspan != 0xFFFFFFFFu;
+    const uint32_t wspan = fast ? T.wspan : 0u;
+    const uint64_t wend = wbase + wspan;
+    if (fast) {
+        bool bad = false;
+        for (uint32_t i = tid; i <= nr; i += NT) {
+            const uint64_t rr = (uint64_t)r0 + i;
+            s_rel[i] = (int32_t)(int64_t)(S.coff[rr] - c0);
+            if (i < nr) {
+                const uint64_t wo = S.woff[rr];
+                const uint32_t ln = S.len[rr];
+                s_wrel[i] = (int32_t)(int64_t)(wo - wbase);
+                s_len[i] = ln;
+                if (i > 0 && wo < wbase) bad = true;
+                if (i + 1 < nr && wo + ((ln + 31u) >> 5) > wend) bad = true;
+            }
+        }
+        for (uint32_t i = tid; i < wspan; i += NT) s_words[i] = S.words[wbase + i];
+        fast = !__syncthreads_or(bad);
+    } else {
+        __syncthreads();
+    }
+
+    uint32_t lo[ITEMS], vals[ITEMS], binrank[ITEMS];
+    // (two instantiations: the address space of the packed words -- LDS or global -- must be static, a pointer that may
+    // be either compiles to flat loads)
+    if (fast) nw_extract<true, HAS_VAL>(S, L, k_, tid, nch, c0, r0, nr, s_rel, s_wrel, s_len, s_words, lhist, lo, vals, binrank);
+    else nw_extract<false, HAS_VAL>(S, L, k_, tid, nch, c0, r0, nr, s_rel, s_wrel, s_len, s_words, lhist, lo, vals, binrank);
+    __syncthreads();  // histogram complete; the read tables may be overwritten by the stage
+
+    // scan of the 1024 bin counts (one bin per thread) and of the non-empty flags; reservation of the tile's run
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t c = lhist[tid];
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    const unsigned long long nzb = __ballot(c != 0);
+    if (lane == 63) scan_tmp[wave] = incl;
+    if (lane == 0) scan_tmp[32 + wave] = (uint32_t)__popcll(nzb);
+    __syncthreads();
+    uint32_t wb = 0, staged = 0, nzbase = 0;
+    for (int w = 0; w < NT / 64; ++w) {
+        if (w < wave) {
+            wb += scan_tmp[w];
+            nzbase += scan_tmp[32 + w];
+        }
+        staged += scan_tmp[w];
+    }
+    const uint32_t ex = wb + incl - c;
+    lstart[tid] = ex;
+    uint32_t greserve = 0;
+    if (c) {
+        greserve = atomicAdd(&cursor[tid], c);
+        nz[nzbase + (uint32_t)__popcll(nzb & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+        atomicOr(&mark[ex >> 6], 1ull << (ex & 63u));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        if (binrank[i] != 0xFFFFFFFFu) {
+            const uint32_t pos = lstart[binrank[i] >> 16] + (binrank[i] & 0xFFFFu);
+            stage[pos] = lo[i];
+            if (HAS_VAL) vstage[pos] = (uint8_t)vals[i];
+        }
+    }
+    goff[tid] = greserve - ex;
+    {
+        // first staged position of this bin that no longer fits its slot
+        const int64_t room = (int64_t)((uint64_t)tid * L.slot_stride + L.slot_cap) - (int64_t)greserve;
+        lhist[tid] = (uint32_t)(int32_t)(room < -(int64_t)0x7FFF0000 ? -(int64_t)0x7FFF0000 : room) + ex;
+    }
+    if (wave == 0) {  // marks before every 64-position word: lane l owns words WPL*l .. WPL*l + WPL-1
+        constexpr int WPL = (MW + 63) / 64;
+        uint32_t p[WPL], tot = 0;
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) {
+            const int idx = lane * WPL + j;
+            p[j] = tot;
+            tot += idx < MW ? (uint32_t)__popcll(mark[idx]) : 0u;
+        }
+        uint32_t inc2 = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(inc2, d, 64);
+            if (lane >= d) inc2 += t;
+        }
+        const uint32_t lb = inc2 - tot;
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) {
+            const int idx = lane * WPL + j;
+            if (idx < MW) mbase[idx] = (uint16_t)(lb + p[j]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t pos = (uint32_t)i * NT + tid;
+        if (pos < staged) {
+            const uint32_t w = pos >> 6;  // uniform in the wave: its 64 lanes cover one mark word
+            const uint32_t r = (uint32_t)mbase[w] + (uint32_t)__popcll(mark[w] & ((2ull << lane) - 1ull)) - 1u;
+            const uint32_t b = nz[r];
+            const uint32_t rec = stage[pos];
+            if ((int32_t)pos >= (int32_t)lhist[b]) {
+                const uint32_t sp = atomicAdd(L.spill_count, 1u);
+                if (sp < L.spill_cap) {
+                    reinterpret_cast<uint64_t *>(L.spill_keys)[sp] = nw_key(b, rec, hb);
+                    if (HAS_VAL) L.spill_vals[sp] = vstage[pos];
+                }
+            } else {
+                const uint32_t g = goff[b] + pos;
+                out[g] = rec;
+                if (HAS_VAL) vout[g] = vstage[pos];
+            }
+        }
+    }
+}
+
+static size_t part_reads_narrow_smem(bool has_val) {
+    const size_t tables = sizeof(uint32_t) * 3 * (kRdSlots + 2) + sizeof(uint64_t) * (kRdWords + 1 + 2);
+    const size_t stage = (size_t)kNwTile * (has_val ? 5 : 4);
+    const size_t fixed = sizeof(uint32_t) * (3 * kNwBins1 + 64) + (size_t)(kNwTile / 64) * (8 + 2) + (size_t)kNwBins1 * 2;
+    return fixed + std::max(tables, stage);
+}
+
+// Level 2: one tile (<= 16384 records) of one segment -> the bucket slots of that segment.  Everything derives from lo.
+constexpr int kNw2Threads = 1024;
+constexpr int kNw2Items = 16;
+constexpr int kNw2Tile = kNw2Threads * kNw2Items;
+
+template <bool HAS_VAL>
+__global__ __launch_bounds__(kNw2Threads) void k_part_narrow2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ vin,
+                                                             const uint4 *__restrict__ desc, PartLevel L,
+                                                             uint32_t *__restrict__ cursor, uint32_t *__restrict__ out,
+                                                             uint32_t *__restrict__ vout) {
+    constexpr int NT = kNw2Threads, ITEMS = kNw2Items, MAXB = kMaxBins;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *lstart = lhist + MAXB;
+    uint32_t *goff = lstart + MAXB;
+    uint32_t *scan_tmp = goff + MAXB;
+    uint32_t *stage = scan_tmp + 32;
+    uint32_t *vstage = stage + kNw2Tile;
+    const uint32_t tid = threadIdx.x;
+    const int hb = L.narrow_hb;
+    const uint4 d = desc[blockIdx.x];  // first record, records, bins of the segment | segment << 16, flat index of bin 0
+    const uint32_t begin = d.x, count = d.y, nb = d.z & 0xFFFFu, seg = d.z >> 16, gbin0 = d.w;
+    lhist[tid] = 0;  // NT == MAXB
+    __syncthreads();
+    uint32_t lo[ITEMS], vals[ITEMS], binrank[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {  // all loads first (index clamped into the tile)
+        const uint32_t local = (uint32_t)i * NT + tid;
+        const uint32_t at = begin + (local < count ? local : count - 1u);
+        lo[i] = in[at];
+        vals[i] = HAS_VAL ? vin[at] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        asm volatile("" : "+v"(lo[i]));
+        if (HAS_VAL) asm volatile("" : "+v"(vals[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t local = (uint32_t)i * NT + tid;
+        binrank[i] = 0xFFFFFFFFu;
+        if (local < count) {
+            const uint32_t b = __umulhi(nw_p2(nw_mix(lo[i]), hb), nb);
+            const uint32_t rank = atomicAdd(&lhist[b], 1u);
+            binrank[i] = (b << 16) | rank;
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t c = tid < nb ? lhist[tid] : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const uint32_t t = __shfl_up(incl, dd, 64);
+        if (lane >= dd) incl += t;
+    }
+    if (lane == 63) scan_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t wb = 0, staged = 0;
+    for (int w = 0; w < NT / 64; ++w) {
+        if (w < wave) wb += scan_tmp[w];
+        staged += scan_tmp[w];
+    }
+    const uint32_t ex = wb + incl - c;
+    if (tid < nb) lstart[tid] = ex;
+    const uint32_t greserve = c ? atomicAdd(&cursor[gbin0 + tid], c) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        if (binrank[i] != 0xFFFFFFFFu) {
+            const uint32_t pos = lstart[binrank[i] >> 16] + (binrank[i] & 0xFFFFu);
+            stage[pos] = lo[i];
+            if (HAS_VAL) vstage[pos] = vals[i];
+        }
+    }
+    if (tid < nb) {
+        goff[tid] = greserve - ex;
+        const int64_t room = (int64_t)((uint64_t)(gbin0 + tid) * L.slot_stride + L.slot_cap) - (int64_t)greserve;
+        lhist[tid] = (uint32_t)(int32_t)(room < -(int64_t)0x7FFF0000 ? -(int64_t)0x7FFF0000 : room) + ex;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t pos = (uint32_t)i * NT + tid;
+        if (pos < staged) {
+            const uint32_t rec = stage[pos];
+            const uint32_t b = __umulhi(nw_p2(nw_mix(rec), hb), nb);
+            if ((int32_t)pos >= (int32_t)lhist[b]) {
+                const uint32_t sp = atomicAdd(L.spill_count, 1u);
+                if (sp < L.spill_cap) {
+                    reinterpret_cast<uint64_t *>(L.spill_keys)[sp] = nw_key(seg, rec, hb);
+                    if (HAS_VAL) L.spill_vals[sp] = vstage[pos];
+                }
+            } else {
+                const uint32_t g = goff[b] + pos;
+                out[g] = rec;
+                if (HAS_VAL) vout[g] = vstage[pos];
+            }
+        }
+    }
+}
+
+static size_t part_narrow2_smem(bool has_val) {
+    return sizeof(uint32_t) * (3 * kMaxBins + 32) + (size_t)kNw2Tile * 4 * (has_val ? 2 : 1);
+}
+
+// level-2 tile descriptors of the narrow path: like k_tile_desc, with the segment id beside the bin count
+__global__ void k_tile_desc_narrow(TileMap M, const uint32_t *__restrict__ seg_nb2, const uint32_t *__restrict__ seg_bin_start,
+                                   uint32_t tile_size, uint4 *__restrict__ desc) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M.ntiles) return;
+    uint32_t lo = 0, hi = M.nseg;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (M.seg_tile_start[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t b = M.seg_off[lo] + (t - M.seg_tile_start[lo]) * tile_size;
+    const uint32_t e = M.seg_off[lo] + M.seg_size[lo];
+    desc[t] = make_uint4(b, (e - b) < tile_size ? (e - b) : tile_size, seg_nb2[lo] | (lo << 16), seg_bin_start[lo]);
+}
+
+// Dedup of one bucket of 4-byte records in an LDS table (32-bit ds_cmpst); the distinct records leave as 8-byte keys
+// rebuilt from (segment of the bucket, lo).  The all-ones record (16 x T) is the table's empty marker and is counted
+// on the side.
+constexpr int kNwHashThreads = 512;
+constexpr int kNwHashItems = 16;  // 8192 records per bucket
+constexpr uint32_t kNwHashSlots = 8192;
+
+template <int OP>
+__global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(const uint32_t *__restrict__ buf,
+                                                                 const uint32_t *__restrict__ vals, BucketArgs A,
+                                                                 const uint16_t *__restrict__ bucket_seg, int hb) {
+    constexpr bool IN_VAL = OP >= 2;
+    constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *pay = tab + kNwHashSlots;
+    uint32_t *scan_tmp = pay + (OP != 0 ? kNwHashSlots : 0);  // [0..7] wave totals, [12] payload of the all-ones record,
+                                                              // [13] its presence, [14] give-up flag, [15] output base
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    uint32_t start, n;
+    bucket_range(A, b, &start, &n);
+    if (n == 0) {
+        if (tid == 0) A.dcount[b] = 0;
+        return;
+    }
+    if (n > (uint32_t)(kNwHashThreads * kNwHashItems)) {
+        if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
+        return;
+    }
+    for (uint32_t s = tid; s < kNwHashSlots; s += kNwHashThreads) {
+        tab[s] = EMPTY;
+        if (OP != 0) pay[s] = 0;
+    }
+    if (tid < 4) scan_tmp[12 + tid] = 0;
+    __syncthreads();
+    uint32_t kk[kNwHashItems], vv[kNwHashItems];
+#pragma unroll
+    for (int i = 0; i < kNwHashItems; ++i) {
+        const uint32_t p = (uint32_t)(i * kNwHashThreads + tid);
+        const uint32_t at = start + (p < n ? p : n - 1u);
+        kk[i] = buf[at];
+        vv[i] = IN_VAL ? vals[at] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < kNwHashItems; ++i) {
+        const uint32_t p = (uint32_t)(i * kNwHashThreads + tid);
+        if (p < n) {
+            if (kk[i] == EMPTY) {
+                scan_tmp[13] = 1;
+                if (OP == 1) atomicAdd(&scan_tmp[12], 1u);
+                else if (OP == 2) atomicAdd(&scan_tmp[12], vv[i]);
+                else if (OP == 3) atomicOr(&scan_tmp[12], vv[i]);
+                continue;
+            }
+            uint32_t slot = nw_slot(nw_mix(kk[i])) & (kNwHashSlots - 1);
+            uint32_t probes = 0;
+            for (;;) {
+                const uint32_t old = atomicCAS(&tab[slot], EMPTY, kk[i]);
+                if (old == EMPTY || old == kk[i]) break;
+                slot = (slot + 1) & (kNwHashSlots - 1);
+                if (++probes > kHashMaxProbes) {
+                    scan_tmp[14] = 1;
+                    break;
+                }
+            }
+            if (OP == 1) atomicAdd(&pay[slot], 1u);
+            else if (OP == 2) atomicAdd(&pay[slot], vv[i]);
+            else if (OP == 3) atomicOr(&pay[slot], vv[i]);
+        }
+    }
+    __syncthreads();
+    if (scan_tmp[14]) {  // the table is (nearly) full: nothing has been written, the caller takes over
+        if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
+        return;
+    }
+    constexpr int SPT = kNwHashSlots / kNwHashThreads;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) cnt += tab[j * kNwHashThreads + tid] != EMPTY ? 1u : 0u;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const uint32_t t = __shfl_up(incl, dd, 64);
+        if (lane >= dd) incl += t;
+    }
+    if (lane == 63) scan_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (int j = 0; j < kNwHashThreads / 64; ++j) {
+        if (j < wave) wbase += scan_tmp[j];
+        total += scan_tmp[j];
+    }
+    const uint32_t extra = scan_tmp[13] ? 1u : 0u;
+    if (tid == 0) scan_tmp[15] = atomicAdd(A.out_total, total + extra);
+    __syncthreads();
+    const uint32_t obase = scan_tmp[15];
+    uint64_t *okeys = reinterpret_cast<uint64_t *>(A.out_keys);
+    const uint32_t seg = bucket_seg[b];
+    uint32_t o = obase + wbase + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+        const uint32_t rec = tab[j * kNwHashThreads + tid];
+        if (rec != EMPTY) {
+            okeys[o] = nw_key(seg, rec, hb);
+            if (OP != 0) A.out_vals[o] = pay[j * kNwHashThreads + tid];
+            ++o;
+        }
+    }
+    if (tid == 0) {
+        if (extra) {
+            okeys[obase + total] = nw_key(seg, EMPTY, hb);
+            if (OP != 0) A.out_vals[obase + total] = scan_tmp[12];
+        }
+        A.dcount[b] = total + extra;
+    }
+}
+
+template <int OP>
+static size_t bucket_hash32_smem() {
+    return sizeof(uint32_t) * kNwHashSlots * (OP != 0 ? 2 : 1) + sizeof(uint32_t) * 16;
+}
+
+// 4-byte records of one segment -> 8-byte keys (overflowing slots are reprocessed by the exact path on a key array)
+__global__ void k_nw_widen(const uint32_t *__restrict__ in, uint32_t n, uint32_t seg, int hb, uint64_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = nw_key(seg, in[i], hb);
+}
+
+// ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------
 // ODD on purpose: in the blocked phases thread t reads records t*ITEMS + i, i.e. lanes are ITEMS*W*2
@@ -2018,6 +2530,19 @@ struct MsdRunner {
             b1 = ref_bits;
             nb1 = 1u << b1;
         }
+        // narrow stage A: reads, 8-byte keys of 33..42 bits, slot mode, one pass -> 4-byte records between the levels
+        // (1024 level-1 segments whatever the size: the segment carries the key bits the record drops)
+        const char *smin_nw = getenv("BBK_SLOTS_MIN");
+        const uint64_t slots_min_nw = smin_nw ? strtoull(smin_nw, nullptr, 10) : (1ull << 22);
+        const int nw_hb = (int)(2 * k) - 32;
+        static const bool no_narrow = getenv("BBK_NO_NARROW") != nullptr;  // A/B switch
+        const bool narrow = W == 1 && from_reads && !ranged && !has_dst && nw_hb >= 1 && nw_hb <= 10 && slots_ok &&
+                            dmode == MSD_HASH && use_hash_dedup() && N >= slots_min_nw && !no_narrow &&
+                            (double)N / fill * 1.1 + (double)N < 4.2e9 && (double)N / kNwBins1 / target < 0.75 * kMaxBins;
+        if (narrow) {
+            b1 = 10;
+            nb1 = kNwBins1;
+        }
         const bool verbose = getenv("BBK_VERBOSE") != nullptr;
         if (want / nb1 > 0.75 * kMaxBins) {  // would need a third level: leave to the LSD path
             if (verbose) fprintf(stderr, "[bbk] msd declines: N=%llu needs more than two levels\n", (unsigned long long)N);
@@ -2027,7 +2552,8 @@ struct MsdRunner {
 
         // level-1 tiles cover the whole instance space; a range pass keeps its share of every tile.  Reads:
         // a tile is `threads` chunks, so the histogram (512 threads) and the scatter (1024) have their own tables
-        const uint32_t ntiles1 = from_reads ? (uint32_t)((n_chunks + kRdThreads - 1) / kRdThreads)
+        const uint32_t rd_tile = narrow ? (uint32_t)kNwChunks : (uint32_t)kRdThreads;  // chunks of a level-1 tile
+        const uint32_t ntiles1 = from_reads ? (uint32_t)((n_chunks + rd_tile - 1) / rd_tile)
                                             : (uint32_t)((Ntot + kPartTileK - 1) / kPartTileK);
         const uint32_t ntiles1h = (uint32_t)((n_chunks + kRdHistThreads - 1) / kRdHistThreads);
         DevBuf tiles_h;
@@ -2037,7 +2563,7 @@ struct MsdRunner {
             tiles_h.alloc(((size_t)ntiles1h + 1) * sizeof(RdTile));
             if (ntiles1) {
                 hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1 + 255) / 256), dim3(256), 0, ctx->stream, coff.as<uint64_t>(),
-                                   rd->d_woff, rd->d_len, rd->n, (uint64_t)ntiles1, (uint32_t)kRdThreads,
+                                   rd->d_woff, rd->d_len, rd->n, (uint64_t)ntiles1, rd_tile,
                                    (uint32_t)RdCfg<W>::CH, k, (uint32_t)kRdSlots, (uint32_t)kRdWords,
                                    tile_read.as<RdTile>());
                 hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1h + 255) / 256), dim3(256), 0, ctx->stream,
@@ -2063,11 +2589,13 @@ struct MsdRunner {
         const uint64_t slots_min = smin ? strtoull(smin, nullptr, 10) : (1ull << 22);
         const bool slots = slots_ok && !has_dst && dmode == MSD_HASH && (use_hash_dedup() || use_hashidx_dedup()) && nb1 > 1 &&
                            N >= slots_min && (double)N / fill * 1.1 + (double)N < 4.2e9;  // u32 slot offsets
+        BBK_REQUIRE(!narrow || slots, BBK_ERR_INTERNAL, "narrow records need the slot mode");
         const uint32_t seg_cap = slots ? ((uint32_t)((double)N / nb1 * 1.01) + 8192u) | 1u : 0u;
-        const uint32_t cap2 = bucket_cap();
+        const uint32_t cap2 = narrow ? (uint32_t)(kNwHashThreads * kNwHashItems) : bucket_cap();
         // bucket slots 256 B further apart than their capacity: with a power-of-two-ish stride every bucket's
         // fill front sits in the same HBM channel (level-2 scatter measured 10 % slower)
-        const uint32_t stride2 = cap2 + (uint32_t)(256 / rec);
+        const size_t rec_ab = narrow ? 4 : rec;  // record width between the levels
+        const uint32_t stride2 = cap2 + (uint32_t)(256 / rec_ab);
         DevBuf spill_k, spill_v, spill_n;  // spill_n: u32 counters [0] spilled records [1] records written by the
                                            // dedup kernels [2] buckets left to the caller
         const uint32_t spill_cap = slots ? (uint32_t)(N / 8 + 65536) : 0u;
@@ -2082,6 +2610,7 @@ struct MsdRunner {
             L1.spill_vals = spill_v.as<uint32_t>();
             L1.spill_count = spill_n.as<uint32_t>();
             L1.spill_cap = spill_cap;
+            L1.narrow_hb = narrow ? nw_hb : 0;
         }
 
         // ---- level 1: histogram (exact mode), offsets, scatter
@@ -2123,13 +2652,29 @@ struct MsdRunner {
         BBK_HIP(hipMemcpyAsync(cur1.p, off1.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
 
         const uint64_t nA = slots ? (uint64_t)nb1 * seg_cap : N;  // records bufA holds (slot layout has gaps)
-        DevBuf bufA(nA * rec), bufB, valA, valB;
+        DevBuf bufA(nA * rec_ab), bufB, valA, valB;
         const bool need_vbuf = has_val || op != MSD_OP_NONE;
         if (has_val) valA.alloc(nA * 4);
         {
             const double pb = (from_reads ? (double)rd->n_words * 8 : (double)N * (rec + (has_val ? 4 : 0))) +
                               (double)N * (rec + (has_val ? 4 : 0));
-            if (from_reads) {
+            if (narrow) {
+                if constexpr (W == 1) {
+                    const double pbn = (double)rd->n_words * 8 + (double)N * (4 + (has_val ? 4 : 0));
+                    const size_t sm = part_reads_narrow_smem(has_val);
+                    KernelTimer t(ctx, "part_scatter1_reads", pbn);
+                    if (has_val) {
+                        auto fn = k_part_reads_narrow<true>;
+                        BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+                        hipLaunchKernelGGL(fn, dim3(ntiles1), dim3(kNwThreads), sm, ctx->stream, S, L1, cur1.as<uint32_t>(), bufA.as<uint32_t>(), valA.as<uint32_t>());
+                    } else {
+                        auto fn = k_part_reads_narrow<false>;
+                        BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+                        hipLaunchKernelGGL(fn, dim3(ntiles1), dim3(kNwThreads), sm, ctx->stream, S, L1, cur1.as<uint32_t>(), bufA.as<uint32_t>(), (uint32_t *)nullptr);
+                    }
+                    check_launch("k_part_reads_narrow");
+                }
+            } else if (from_reads) {
                 if (has_val) launch_part_reads<true, false>("part_scatter1_reads", pb, ntiles1, S, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
                 else launch_part_reads<false, false>("part_scatter1_reads", pb, ntiles1, S, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
             } else {
@@ -2166,8 +2711,9 @@ struct MsdRunner {
         }
         tstart[0] = 0;
         sbin[0] = 0;
+        const uint32_t tile2 = narrow ? (uint32_t)kNw2Tile : kPartTileK;
         for (uint32_t b = 0; b < nb1; ++b) {
-            tstart[b + 1] = tstart[b] + (h1[b] + kPartTileK - 1) / kPartTileK;
+            tstart[b + 1] = tstart[b] + (h1[b] + tile2 - 1) / tile2;
             snb2[b] = (uint32_t)std::min<double>(kMaxBins, std::max(1.0, std::ceil((double)h1[b] / target)));
             sbin[b + 1] = sbin[b] + snb2[b];
         }
@@ -2186,15 +2732,19 @@ struct MsdRunner {
         TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), seg_size.as<uint32_t>(), nb1, N, ntiles2, 1, nullptr, 0, 0};
         DevBuf desc2((size_t)ntiles2 * sizeof(uint4) + 16);
         if (ntiles2) {
-            hipLaunchKernelGGL(k_tile_desc, dim3((ntiles2 + 255) / 256), dim3(256), 0, ctx->stream, M2, seg_nb2.as<uint32_t>(),
-                               seg_bin.as<uint32_t>(), kPartTileK, desc2.as<uint4>());
+            if (narrow)
+                hipLaunchKernelGGL(k_tile_desc_narrow, dim3((ntiles2 + 255) / 256), dim3(256), 0, ctx->stream, M2,
+                                   seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), tile2, desc2.as<uint4>());
+            else
+                hipLaunchKernelGGL(k_tile_desc, dim3((ntiles2 + 255) / 256), dim3(256), 0, ctx->stream, M2, seg_nb2.as<uint32_t>(),
+                                   seg_bin.as<uint32_t>(), kPartTileK, desc2.as<uint4>());
             check_launch("k_tile_desc");
         }
         M2.desc = desc2.as<uint4>();
         DevBuf hist2((size_t)nbuckets * 4 + 16), boff(((size_t)nbuckets + 1) * 4 + 16);
         const uint64_t nB = slots ? (uint64_t)nbuckets * stride2 : N;
         if (slots) BBK_REQUIRE(nB + N < (1ull << 32), BBK_ERR_INTERNAL, "slot layout exceeds 32-bit offsets");
-        bufB.alloc(nB * rec);
+        bufB.alloc(nB * rec_ab);
         if (need_vbuf) valB.alloc(nB * 4);
         if (!slots) {
             BBK_HIP(hipMemsetAsync(hist2.p, 0, (size_t)nbuckets * 4 + 16, ctx->stream));
@@ -2222,8 +2772,27 @@ struct MsdRunner {
             L2.spill_vals = spill_v.as<uint32_t>();
             L2.spill_count = spill_n.as<uint32_t>();
             L2.spill_cap = spill_cap;
+            L2.narrow_hb = narrow ? nw_hb : 0;
         }
-        {
+        if (narrow) {
+            if (ntiles2) {
+                const double pb = 2.0 * (double)N * (4 + (has_val ? 4 : 0));
+                const size_t sm = part_narrow2_smem(has_val);
+                KernelTimer t(ctx, "part_scatter2", pb);
+                if (has_val) {
+                    auto fn = k_part_narrow2<true>;
+                    BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+                    hipLaunchKernelGGL(fn, dim3(ntiles2), dim3(kNw2Threads), sm, ctx->stream, bufA.as<uint32_t>(), valA.as<uint32_t>(),
+                                       desc2.as<uint4>(), L2, hist2.as<uint32_t>(), bufB.as<uint32_t>(), valB.as<uint32_t>());
+                } else {
+                    auto fn = k_part_narrow2<false>;
+                    BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+                    hipLaunchKernelGGL(fn, dim3(ntiles2), dim3(kNw2Threads), sm, ctx->stream, bufA.as<uint32_t>(), (const uint32_t *)nullptr,
+                                       desc2.as<uint4>(), L2, hist2.as<uint32_t>(), bufB.as<uint32_t>(), (uint32_t *)nullptr);
+                }
+                check_launch("k_part_narrow2");
+            }
+        } else {
             const double pb = 2.0 * (double)N * (rec + (has_val ? 4 : 0));
             if (has_val) launch_part<true, false>("part_scatter2", pb, ntiles2, bufA.as<Key<W>>(), valA.as<uint32_t>(), M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), valB.as<uint32_t>());
             else launch_part<false, false>("part_scatter2", pb, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), nullptr);
@@ -2263,7 +2832,34 @@ struct MsdRunner {
             A.dup_flag = dupf.as<uint32_t>();
             A.strip_mask = strip_mask;
         }
-        bucket_dispatch<false>(nbuckets, bufB.as<Key<W>>(), valB.as<uint32_t>(), A, bb);
+        DevBuf bseg;
+        std::vector<uint16_t> h_bseg;
+        if (narrow) {
+            if constexpr (W == 1) {
+                h_bseg.resize((size_t)nbuckets + 1);
+                for (uint32_t b = 0; b < nb1; ++b)
+                    for (uint32_t g = sbin[b]; g < sbin[b + 1]; ++g) h_bseg[g] = (uint16_t)b;
+                bseg.alloc(((size_t)nbuckets + 1) * 2);
+                BBK_HIP(hipMemcpyAsync(bseg.p, h_bseg.data(), (size_t)nbuckets * 2, hipMemcpyHostToDevice, ctx->stream));
+                const double bbn = (double)N * (4 + (has_val ? 4 : 0));
+                auto launch32 = [&](auto fn, size_t sm) {
+                    BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+                    KernelTimer t(ctx, "lds_dedup", bbn);
+                    hipLaunchKernelGGL(fn, dim3(nbuckets), dim3(kNwHashThreads), sm, ctx->stream, bufB.as<uint32_t>(),
+                                       valB.as<uint32_t>(), A, bseg.as<uint16_t>(), nw_hb);
+                    check_launch("k_bucket_hash32");
+                };
+                if (nbuckets) switch (op) {
+                    case MSD_OP_NONE: launch32(k_bucket_hash32<0>, bucket_hash32_smem<0>()); break;
+                    case MSD_OP_COUNT: launch32(k_bucket_hash32<1>, bucket_hash32_smem<1>()); break;
+                    case MSD_OP_SUM: launch32(k_bucket_hash32<2>, bucket_hash32_smem<2>()); break;
+                    case MSD_OP_OR: launch32(k_bucket_hash32<3>, bucket_hash32_smem<3>()); break;
+                    default: BBK_REQUIRE(false, BBK_ERR_ARG, "bad reduce op");
+                }
+            }
+        } else {
+            bucket_dispatch<false>(nbuckets, bufB.as<Key<W>>(), valB.as<uint32_t>(), A, bb);
+        }
 
         // buckets the first pass left alone: listed on the device, only the (short) list comes to the host
         constexpr uint32_t kFlagCap = 65536;
@@ -2350,8 +2946,9 @@ struct MsdRunner {
             uint64_t n_extra = (uint64_t)n_spill + (uint64_t)over_seg.size() * seg_cap;
             for (uint32_t f : bkt_fill) n_extra += f;
             if (verbose)
-                fprintf(stderr, "[bbk] msd slots N=%llu nb1=%u seg_cap=%u buckets=%u spill=%u over_seg=%zu over_bkt=%zu\n",
-                        (unsigned long long)N, nb1, seg_cap, nbuckets, n_spill, over_seg.size(), over_bkt.size());
+                fprintf(stderr, "[bbk] msd slots%s N=%llu nb1=%u seg_cap=%u buckets=%u spill=%u over_seg=%zu over_bkt=%zu\n",
+                        narrow ? " (narrow records)" : "", (unsigned long long)N, nb1, seg_cap, nbuckets, n_spill,
+                        over_seg.size(), over_bkt.size());
             if (n_extra > N / 2) {  // most of the input overflowed (a handful of distinct k-mers): not for this mode
                 if (verbose) fprintf(stderr, "[bbk] msd slots: %llu of %llu records overflowed, exact mode\n",
                                      (unsigned long long)n_extra, (unsigned long long)N);
@@ -2363,8 +2960,15 @@ struct MsdRunner {
                 DevBuf ek(n_extra * rec), ev;
                 if (has_val || (tiny && op != MSD_OP_NONE)) ev.alloc(n_extra * 4 + 16);
                 uint64_t o = 0;
-                auto put = [&](const void *ksrc, const uint32_t *vsrc, uint64_t first, uint64_t cnt) {
+                // narrow path: slots hold 4-byte records, widened with the segment they belong to (seg < 0: 8-byte keys)
+                auto put = [&](const void *ksrc, const uint32_t *vsrc, uint64_t first, uint64_t cnt, int seg = -1) {
                     if (!cnt) return;
+                    if (seg >= 0) {
+                        hipLaunchKernelGGL(k_nw_widen, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                                           (const uint32_t *)ksrc + first, (uint32_t)cnt, (uint32_t)seg, nw_hb,
+                                           ek.as<uint64_t>() + o);
+                        check_launch("k_nw_widen");
+                    } else
                     BBK_HIP(hipMemcpyAsync(ek.as<char>() + o * rec, (const char *)ksrc + first * rec, cnt * rec,
                                            hipMemcpyDeviceToDevice, ctx->stream));
                     if (has_val)
@@ -2373,9 +2977,10 @@ struct MsdRunner {
                     o += cnt;
                 };
                 put(spill_k.p, spill_v.as<uint32_t>(), 0, n_spill);
-                for (uint32_t b : over_seg) put(bufA.p, valA.as<uint32_t>(), (uint64_t)b * seg_cap, seg_cap);
+                for (uint32_t b : over_seg) put(bufA.p, valA.as<uint32_t>(), (uint64_t)b * seg_cap, seg_cap, narrow ? (int)b : -1);
                 for (size_t i = 0; i < over_bkt.size(); ++i)
-                    put(bufB.p, valB.as<uint32_t>(), (uint64_t)over_bkt[i] * stride2, bkt_fill[i]);
+                    put(bufB.p, valB.as<uint32_t>(), (uint64_t)over_bkt[i] * stride2, bkt_fill[i],
+                        narrow ? (int)h_bseg[over_bkt[i]] : -1);
                 if (tiny) {
                     // the usual case (one or two crowded buckets): ONE workgroup sorts + reduces all of it in LDS,
                     // instead of a whole partition pipeline for a few thousand records

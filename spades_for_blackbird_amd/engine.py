@@ -38,6 +38,28 @@ def lib_path():
     return os.environ.get("BBK_LIB") or os.path.join(_HERE, "libbbk.so")
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64, libbbk.so links the system ones
+    (/opt/rocm).  Two HSA runtimes cannot both drive the GPU from one process: whichever initialises second sees "no
+    devices" (observed: engine first, then torch -> "No HIP GPUs are available").  Python users of this binding
+    normally have torch in the process (bench.py, distributed.py), so when torch is installed its HIP runtime is put
+    into the global symbol scope BEFORE libbbk.so is loaded and libbbk's hip* calls bind to it -- one runtime, in
+    either order.  Without torch (or for the C++ CLIs) the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand) and not os.environ.get("BBK_SYSTEM_HIP"):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """Loads libbbk.so; raises BBKError if it has not been built (no fallback exists)."""
     global _LIB
@@ -47,6 +69,7 @@ def load_library():
     if not os.path.exists(p):
         raise BBKError("libbbk.so is missing: build it with `python -m spades_for_blackbird_amd.build` "
                        "(hipcc --offload-arch=gfx950); this engine has no CPU fallback")
+    _share_torch_hip_runtime()
     L = C.CDLL(p)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     L.bbk_last_error.restype = C.c_char_p

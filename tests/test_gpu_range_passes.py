@@ -52,7 +52,7 @@ ctx = B.Context(0)
 reads = synth_reads(4000, read_len=150, genome_len=30000, sub_rate=0.01, seed=5, n_rate=0.001)
 # heavy repeats: single k-mers with tens of thousands of instances overflow their bucket / segment slots
 reads += ["A" * 150] * 400 + ["ACGT" * 37] * 300 + ["AC" * 75] * 200 + ["ACGGTCA" * 21] * 150
-for k in (21, 33):
+for k in (21, 33, 19):
     r = ctx.reads_from_ascii(reads)
     for flags in (B.BOTH_STRANDS | B.WITH_COUNTS, B.BOTH_STRANDS | B.REFERENCE_ORDER):
         s = ctx.count(r, k, flags)
@@ -90,6 +90,6 @@ def test_forced_slot_mode_with_overflow():
                        timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "SLOTS-OK" in r.stdout
-    lines = [l for l in r.stderr.splitlines() if "msd slots N=" in l]
+    lines = [l for l in r.stderr.splitlines() if "msd slots" in l and " N=" in l]
     assert lines, "the slot mode did not run"
     assert any("spill=0 " not in l for l in lines), "no slot overflowed: the test input is too tame"

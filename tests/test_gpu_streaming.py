@@ -108,3 +108,11 @@ def test_pushed_batches_with_forced_range_passes():
 def test_slot_mode_with_pushed_batches():
     """the histogram-free slot mode + spill reprocessing on every pushed batch and on the merges"""
     _run({"BBK_MERGE_MIN": "0", "BBK_SLOTS_MIN": "0"}, 3000, 20000, (21, 33))
+
+
+def test_narrow_records_all_k():
+    """stage A with 4-byte records between the partition levels (msd.hip "narrow records", 17 <= k <= 21): every k of
+    that range (2k - 32 = 2 .. 10 key bits carried by the segment), with multiplicities, mask payloads (extension
+    index, odd k), heavy repeats that overflow slots, and k = 16 / 22 on either side of the range"""
+    err = _run({"BBK_MERGE_MIN": "0", "BBK_SLOTS_MIN": "0"}, 3000, 20000, (16, 17, 18, 19, 20, 21, 22))
+    assert "narrow" in err
