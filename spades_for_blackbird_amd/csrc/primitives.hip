@@ -150,6 +150,11 @@ void d2h_big(bbk_ctx *ctx, void *dst, const void *src, size_t bytes) {
 
 bool d2f_big(bbk_ctx *ctx, int fd, uint64_t file_off, const void *src, size_t bytes) {
     constexpr size_t kChunk = 32ull << 20;
+    static const int kWriters = [] {
+        const char *e = getenv("BBK_WRITE_THREADS");
+        const int t = e ? atoi(e) : 4;  // measured on tmpfs: 2 -> 3.8, 4 -> 6.4, 8 -> 3.5, 16 -> 4.6 GB/s (one box; the writers share 16 cores)
+        return t < 1 ? 1 : (t > 64 ? 64 : t);
+    }();
     if (bytes == 0) return true;
     if (!ctx->pinned[0]) {
         BBK_HIP(hipHostMalloc(&ctx->pinned[0], kChunk, hipHostMallocDefault));
@@ -176,11 +181,11 @@ bool d2f_big(bbk_ctx *ctx, int fd, uint64_t file_off, const void *src, size_t by
         if (c + 1 < nchunks) issue(c + 1);
         const size_t off = c * kChunk, sz = std::min(kChunk, bytes - off);
         // several writers per chunk: a single pwrite stream into tmpfs runs at ~1/3 of what the box can do
-        const int T = 4;
-        const size_t part = (sz + T - 1) / T;
+        const int T = kWriters;
+        const size_t part = (((sz + T - 1) / T) + 4095) & ~(size_t)4095;  // page-aligned shares
 #pragma omp parallel for num_threads(T) schedule(static)
         for (int t = 0; t < T; ++t) {
-            size_t o = (size_t)t * part;
+            size_t o = std::min(sz, (size_t)t * part);
             const size_t e = std::min(sz, o + part);
             while (o < e) {
                 const ssize_t w = pwrite(fd, (const char *)ctx->pinned[c & 1] + o, e - o, (off_t)(file_off + off + o));

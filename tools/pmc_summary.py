@@ -17,6 +17,9 @@ import re
 import sys
 
 FAMILY = [  # k_part_reads<W, HAS_VAL, HIST_ONLY>, k_part<W, HAS_VAL, HIST_ONLY, LVL1>
+    (r"k_part_reads_narrow", "part_scatter1_reads"),
+    (r"k_part_narrow2", "part_scatter2"),
+    (r"k_bucket_hash32", "lds_dedup"),
     (r"k_part_reads<\d, (true|false), false>", "part_scatter1_reads"),
     (r"k_part_reads<\d, (true|false), true>", "part_hist1_reads"),
     (r"k_part<\d, (true|false), false, true>", "part_scatter1_keys"),
