@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-gfa", action="store_true", help="skip the (untimed-region) GFA-build wall-time measurement")
     ap.add_argument("--no-e2e", action="store_true", help="skip the CLI wall-time measurement on FASTA input")
     ap.add_argument("--no-k55", action="store_true", help="skip the k=55 (16-byte keys) object")
+    ap.add_argument("--no-meta", action="store_true", help="skip the skewed-metagenome (configs[4] shape) object")
     return ap.parse_args()
 
 
@@ -220,6 +221,35 @@ def e2e(ctx, reads, args):
     finally:
         import shutil
         shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+def metagenome(ctx, args, B, fence):
+    """BASELINE configs[4] shape at one-GPU size: the same number of reads drawn from a skewed community (200 genomes,
+    lengths log-uniform 0.5-8 Mbp, abundances log-normal sigma=2, seed 44: SURVEY 8d), multi-k {21, 33, 55}; per k the
+    step time and what the histogram-free slot mode spilled / had to reprocess under real skew."""
+    r = ctx.reads_synth_meta(args.reads, read_len=args.read_len, seed=44)
+    out = {"workload": "%d x %d bp reads of a synthetic metagenome: 200 genomes, lengths log-uniform 0.5-8 Mbp, "
+                       "abundances log-normal(sigma=2), 0.5 %% substitutions, seed 44; k-mer count only, 1 GPU"
+                       % (args.reads, args.read_len), "per_k": {}}
+    stats = ("stat_slot_records", "stat_slot_spilled", "stat_slot_overflow_segments", "stat_slot_overflow_buckets",
+             "stat_slot_reprocessed")
+    for kk in (21, 33, 55):
+        def st():
+            s = ctx.count(r, kk, B.BOTH_STRANDS | B.REFERENCE_ORDER)
+            return len(s), s
+        n, dt, prof = timed_steps(ctx, st, fence, 1, 2)
+        sv = {f: ctx.profile_get(f) for f in stats}
+        rec = max(1.0, sv["stat_slot_records"]["bytes"])
+        out["per_k"][str(kk)] = {
+            "ms_per_step": dt / 2 * 1e3, "distinct_kmers": n, "value": n / (dt / 2), "unit": "distinct k-mers/s",
+            "slot_mode": {"passes": sv["stat_slot_records"]["launches"] / 2,
+                          "spilled_frac": sv["stat_slot_spilled"]["bytes"] / rec,
+                          "reprocessed_frac": sv["stat_slot_reprocessed"]["bytes"] / rec,
+                          "overflow_segments_per_step": sv["stat_slot_overflow_segments"]["bytes"] / 2,
+                          "overflow_buckets_per_step": sv["stat_slot_overflow_buckets"]["bytes"] / 2},
+            "kernel_ms_per_step": {f: v["ms"] / 2 for f, v in prof.items()}}
+    r.free()
     return out
 
 
@@ -394,6 +424,8 @@ def main():
                            "value": n55 / (dt55 / 2), "unit": "distinct k-mers/s", "dtype": "u128",
                            "kernel_ms_per_step": {f: v["ms"] / 2 for f, v in prof55.items()},
                            "roofline": roofline_of(prof55, 2)}
+        if world == 1 and not args.no_meta and not big:
+            line["metagenome"] = metagenome(ctx, args, B, fence)
         if world == 1 and not args.no_gfa and not big:
             line["gfa_build"] = gfa_build(ctx, reads, k)
         if gfa_sharded:

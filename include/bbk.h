@@ -58,6 +58,9 @@ int bbk_ctx_profile_enable(bbk_ctx *ctx, int on);
 int bbk_ctx_profile_reset(bbk_ctx *ctx);
 int bbk_ctx_profile_get(bbk_ctx *ctx, const char *family, double *ms_total, uint64_t *launches,
                         double *bytes_total);
+/* Event counters are read the same way (launches = events, bytes_total = summed value): "stat_slot_records",
+ * "stat_slot_spilled", "stat_slot_overflow_segments", "stat_slot_overflow_buckets", "stat_slot_reprocessed" -- what the
+ * histogram-free slot mode of stage A placed, spilled and had to reprocess (skewed inputs). */
 
 /* ---- reads: replaces io::EasyStream(file, followed_by_rc=true, handle_Ns=true)
  *      (common/io/reads/io_helper.cpp:19-32) and the binary read cache
@@ -87,6 +90,13 @@ int bbk_reads_from_device(bbk_ctx *ctx, const void *d_words, const void *d_word_
  * (seed_genome), uniform start, strand flip p=0.5, substitution rate sub_rate (seed_reads). */
 int bbk_reads_synth(bbk_ctx *ctx, uint64_t n_reads, uint32_t read_len, uint64_t genome_len, double sub_rate,
                     uint64_t seed_genome, uint64_t seed_reads, bbk_reads **out);
+/* Metagenome-shaped synthetic reads (BASELINE configs[4]): n_genomes random genomes with lengths
+ * log-uniform in [min_len, max_len] and abundances log-normal(sigma) (sigma = 2: three decades of coverage skew);
+ * a read picks its genome with probability ~ abundance x length; read model as bbk_reads_synth.  h_genome_len /
+ * h_abundance (optional, n_genomes entries) receive the drawn community. */
+int bbk_reads_synth_meta(bbk_ctx *ctx, uint64_t n_reads, uint32_t read_len, uint32_t n_genomes, uint64_t min_len,
+                         uint64_t max_len, double sigma, double sub_rate, uint64_t seed, bbk_reads **out,
+                         uint64_t *h_genome_len, double *h_abundance);
 /* SPAdes binary read cache of single reads (<prefix>.seq / <prefix>.off, io::BinaryWriter::ToBinary,
  * common/io/reads/binary_converter.cpp:50-113; record layout Sequence::BinWrite, common/sequence/sequence.hpp:410-442).
  * Its 2-bit words are exactly the device layout: records are copied, not re-encoded. */

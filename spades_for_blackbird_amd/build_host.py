@@ -31,5 +31,20 @@ def build(force=False, verbose=False):
     return out
 
 
+def build_sanitized(force=False):
+    """Host sanitizer build (the reference's SPADES_ENABLE_ASAN option, cmake/options.cmake:18-23): the host-only
+    parser tool compiled with AddressSanitizer + UndefinedBehaviorSanitizer (CPU only: GPU ASAN is not available on
+    this pool).  tests/test_ingest.py runs the parser corner cases through it."""
+    os.makedirs(BIN, exist_ok=True)
+    exe = os.path.join(BIN, "bbk-fastx-dump-asan")
+    srcp = os.path.join(HOST, "fastx_dump_main.cpp")
+    deps = [os.path.join(HOST, h) for h in HEADERS] + [srcp]
+    stale = not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps if os.path.exists(d))
+    if force or stale:
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-fopenmp", "-fsanitize=address,undefined",
+                               "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-o", exe, srcp, "-lz"])
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

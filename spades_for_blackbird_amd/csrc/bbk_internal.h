@@ -149,6 +149,13 @@ struct bbk_ctx {
     std::vector<Pending> pending;
     std::map<std::string, bbk::FamilyStat> stats;
     void resolve_pending();
+    // event counters of the path (read back like a kernel family: launches = events, bytes_total = summed value)
+    void add_stat(const char *name, double value) {
+        if (!profiling) return;
+        bbk::FamilyStat &f = stats[name];
+        f.launches += 1;
+        f.bytes += value;
+    }
     // pinned staging for large device-to-host copies (pageable copies run at a fraction of PCIe)
     void *pinned[2] = {nullptr, nullptr};
     size_t pinned_bytes = 0;

@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -2949,6 +2950,11 @@ struct MsdRunner {
                 fprintf(stderr, "[bbk] msd slots%s N=%llu nb1=%u seg_cap=%u buckets=%u spill=%u over_seg=%zu over_bkt=%zu\n",
                         narrow ? " (narrow records)" : "", (unsigned long long)N, nb1, seg_cap, nbuckets, n_spill,
                         over_seg.size(), over_bkt.size());
+            ctx->add_stat("stat_slot_records", (double)N);
+            ctx->add_stat("stat_slot_spilled", (double)n_spill);
+            ctx->add_stat("stat_slot_overflow_segments", (double)over_seg.size());
+            ctx->add_stat("stat_slot_overflow_buckets", (double)over_bkt.size());
+            ctx->add_stat("stat_slot_reprocessed", (double)n_extra);
             if (n_extra > N / 2) {  // most of the input overflowed (a handful of distinct k-mers): not for this mode
                 if (verbose) fprintf(stderr, "[bbk] msd slots: %llu of %llu records overflowed, exact mode\n",
                                      (unsigned long long)n_extra, (unsigned long long)N);
@@ -3176,15 +3182,19 @@ struct MsdRunner {
         const bool verbose = getenv("BBK_VERBOSE") != nullptr;
         ranges.clear();
         if (dmode == MSD_HASH) {
-            int bits = 1;
-            while ((N >> bits) > limit && bits < 12) ++bits;
-            if ((N >> bits) > limit) return false;
-            for (uint32_t v = 0; v < (1u << bits); ++v) {
+            // equal spans of the 32-bit hash space, as few as fit (not a power of two: 9.6 G records of 16-byte keys take
+            // 10 passes, not 16 -- every pass re-extracts all k-mers of the reads)
+            const uint64_t nr = (N + limit - 1) / limit;
+            if (nr > 4096) return false;
+            const uint64_t span = ((1ull << 32) + nr - 1) / nr;
+            for (uint64_t v = 0; v < nr; ++v) {
                 Sel s;
-                s.lo = v << (32 - bits);
-                s.span = 1u << (32 - bits);
-                s.shl = bits;
-                s.est = (N >> bits) + (N >> (bits + 4)) + 1;
+                const uint64_t lo = v * span, hi = std::min<uint64_t>(1ull << 32, lo + span);
+                if (lo >= hi) break;
+                s.lo = (uint32_t)lo;
+                s.span = (uint32_t)(hi - lo);
+                s.shl = __builtin_clz(s.span - 1u);
+                s.est = (uint64_t)((double)N * (double)(hi - lo) / 4294967296.0 * 1.04) + 1;
                 ranges.push_back(s);
             }
             if (verbose) fprintf(stderr, "[bbk] msd: %llu records in %zu hash ranges\n", (unsigned long long)N, ranges.size());
@@ -3289,7 +3299,11 @@ struct MsdRunner {
             for (const Sel &sr : ranges) {
                 MsdOutput part;
                 Dst dst{out.keys.as<char>() + D * rec, out_vals ? out.vals.as<uint32_t>() + D : nullptr};
+                const double t0k = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
                 const int rv = run(rd, d_keys, d_vals, n_in, with_mask, part, sr, nullptr, dst);
+                if (getenv("BBK_VERBOSE"))
+                    fprintf(stderr, "[bbk] key range: %.3f s\n",
+                            std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0k);
                 if (rv != 1) return false;
                 D += part.n;
                 inst += part.instances;
@@ -3302,9 +3316,13 @@ struct MsdRunner {
             return true;
         }
         std::vector<MsdOutput> parts(ranges.size());
+        const bool verbose = getenv("BBK_VERBOSE") != nullptr;
+        auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         for (size_t v = 0; v < ranges.size(); ++v) {
             MsdOutput &pt = parts[v];
+            const double t0 = wall();
             int rv = run(rd, d_keys, d_vals, n_in, with_mask, pt, ranges[v], nullptr);
+            if (verbose) fprintf(stderr, "[bbk] hash range %zu/%zu: %.3f s\n", v + 1, ranges.size(), wall() - t0);
             if (rv == 3) {
                 slots_ok = false;
                 rv = run(rd, d_keys, d_vals, n_in, with_mask, pt, ranges[v], nullptr);

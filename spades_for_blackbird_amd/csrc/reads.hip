@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -100,6 +101,48 @@ __global__ void k_synth_reads(uint64_t n_reads, uint32_t read_len, uint32_t word
 }
 
 // word offset of every read when the reads are stored one after the other, each starting on a 64-bit word
+// Metagenome-shaped reads (BASELINE configs[4]): read r picks genome g with probability ~ abundance x
+// length (cdf: n_genomes + 1 thresholds scaled to 2^64), a uniform start inside it, strand and substitutions as
+// k_synth_reads.  Genome g is the random sequence seeded with seed_genome ^ mix(g).
+__global__ void k_synth_meta(uint64_t n_reads, uint32_t read_len, uint32_t words_per_read, uint32_t n_genomes,
+                             const uint64_t *__restrict__ cdf, const uint64_t *__restrict__ glen, uint32_t sub_thresh,
+                             uint64_t seed_genome, uint64_t seed_reads, uint64_t *__restrict__ words,
+                             uint64_t *__restrict__ woff, uint32_t *__restrict__ len) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = gid / words_per_read;
+    const uint32_t wj = (uint32_t)(gid % words_per_read);
+    if (r >= n_reads) return;
+    const uint64_t h = splitmix64(seed_reads ^ (r * 0xD1B54A32D192ED03ull));
+    const uint64_t u = splitmix64(h ^ 0x2545F4914F6CDD1Dull);
+    uint32_t lo = 0, hi = n_genomes;  // largest g with cdf[g] <= u
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t g = lo;
+    const uint64_t gseed = seed_genome ^ splitmix64(0x9E3779B97F4A7C15ull * (g + 1));
+    const uint64_t start = (uint64_t)__umul64hi(splitmix64(h), glen[g] - read_len + 1);
+    const bool flip = (h >> 63) != 0;
+    uint64_t w = 0;
+    for (uint32_t j = 0; j < 32; ++j) {
+        const uint32_t p = wj * 32 + j;
+        if (p >= read_len) break;
+        const uint32_t q = flip ? (read_len - 1 - p) : p;
+        uint32_t b = genome_base(gseed, start + q);
+        const uint64_t e = splitmix64(h + 0x632BE59BD9B4E019ull * (q + 1));
+        if ((uint32_t)(e >> 32) < sub_thresh) b = (b + 1 + (uint32_t)(e % 3)) & 3u;
+        if (flip) b = 3 - b;
+        w |= (uint64_t)b << (j << 1);
+    }
+    words[r * words_per_read + wj] = w;
+    if (wj == 0) {
+        woff[r] = r * words_per_read;
+        len[r] = read_len;
+        if (r == n_reads - 1) woff[n_reads] = n_reads * words_per_read;
+    }
+}
+
 __global__ void k_len_to_words(const uint32_t *__restrict__ len, uint64_t n, uint64_t *__restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = ((uint64_t)len[i] + 31u) >> 5;
@@ -380,6 +423,71 @@ int bbk_reads_synth(bbk_ctx *ctx, uint64_t n_reads, uint32_t read_len, uint64_t 
                                n_reads, read_len, wpr, genome_len, thresh, seed_genome, seed_reads,
                                rd->own_words.as<uint64_t>(), rd->own_woff.as<uint64_t>(), rd->own_len.as<uint32_t>());
             bbk::check_launch("k_synth_reads");
+        } else {
+            BBK_HIP(hipMemsetAsync(rd->own_woff.p, 0, sizeof(uint64_t), ctx->stream));
+        }
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        rd->d_words = rd->own_words.as<uint64_t>();
+        rd->d_woff = rd->own_woff.as<uint64_t>();
+        rd->d_len = rd->own_len.as<uint32_t>();
+        *out = guard.release();
+    });
+}
+
+int bbk_reads_synth_meta(bbk_ctx *ctx, uint64_t n_reads, uint32_t read_len, uint32_t n_genomes, uint64_t min_len,
+                         uint64_t max_len, double sigma, double sub_rate, uint64_t seed, bbk_reads **out,
+                         uint64_t *h_genome_len, double *h_abundance) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx && out, BBK_ERR_ARG, "bbk_reads_synth_meta: NULL argument");
+        BBK_REQUIRE(read_len >= 1 && n_genomes >= 1 && n_genomes <= 65536 && min_len >= read_len && max_len >= min_len &&
+                        sigma >= 0 && sub_rate >= 0 && sub_rate < 1,
+                    BBK_ERR_ARG, "bbk_reads_synth_meta: bad shape");
+        BBK_HIP(hipSetDevice(ctx->device));
+        // genome lengths log-uniform in [min_len, max_len], abundances log-normal(sigma) (Box-Muller on splitmix64)
+        std::vector<uint64_t> glen(n_genomes), cdf(n_genomes + 1);
+        std::vector<double> ab(n_genomes), wgt(n_genomes);
+        auto u01 = [](uint64_t x) { return ((double)(bbk::splitmix64(x) >> 11) + 0.5) / 9007199254740992.0; };
+        double tot = 0;
+        for (uint32_t g = 0; g < n_genomes; ++g) {
+            const double a = u01(seed * 3 + 7919ull * g + 1), b1 = u01(seed * 5 + 104729ull * g + 2),
+                         b2 = u01(seed * 7 + 1299709ull * g + 3);
+            glen[g] = (uint64_t)((double)min_len * pow((double)max_len / (double)min_len, a));
+            if (glen[g] < read_len) glen[g] = read_len;
+            const double z = sqrt(-2.0 * log(b1)) * cos(6.283185307179586 * b2);
+            ab[g] = exp(sigma * z);
+            wgt[g] = ab[g] * (double)glen[g];
+            tot += wgt[g];
+        }
+        double acc = 0;
+        for (uint32_t g = 0; g < n_genomes; ++g) {
+            cdf[g] = (uint64_t)(acc / tot * 18446744073709551615.0);
+            acc += wgt[g];
+        }
+        cdf[0] = 0;
+        cdf[n_genomes] = ~0ull;
+        if (h_genome_len) memcpy(h_genome_len, glen.data(), n_genomes * sizeof(uint64_t));
+        if (h_abundance) memcpy(h_abundance, ab.data(), n_genomes * sizeof(double));
+        const uint32_t wpr = (read_len + 31) / 32;
+        auto rd = new bbk_reads();
+        std::unique_ptr<bbk_reads> guard(rd);
+        rd->ctx = ctx;
+        rd->n = n_reads;
+        rd->n_words = n_reads * wpr;
+        rd->bases = n_reads * read_len;
+        rd->own_words.alloc((rd->n_words + 1) * sizeof(uint64_t));
+        rd->own_woff.alloc((n_reads + 1) * sizeof(uint64_t));
+        rd->own_len.alloc((n_reads + 1) * sizeof(uint32_t));
+        bbk::DevBuf d_cdf((n_genomes + 1) * 8), d_glen(n_genomes * 8);
+        BBK_HIP(hipMemcpyAsync(d_cdf.p, cdf.data(), (n_genomes + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(d_glen.p, glen.data(), n_genomes * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (n_reads) {
+            const uint64_t total = n_reads * wpr;
+            const uint32_t thresh = (uint32_t)(sub_rate * 4294967296.0);
+            hipLaunchKernelGGL(bbk::k_synth_meta, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, n_reads,
+                               read_len, wpr, n_genomes, d_cdf.as<uint64_t>(), d_glen.as<uint64_t>(), thresh, seed,
+                               seed ^ 0xA5A5A5A5A5A5A5A5ull, rd->own_words.as<uint64_t>(), rd->own_woff.as<uint64_t>(),
+                               rd->own_len.as<uint32_t>());
+            bbk::check_launch("k_synth_meta");
         } else {
             BBK_HIP(hipMemsetAsync(rd->own_woff.p, 0, sizeof(uint64_t), ctx->stream));
         }

@@ -14,7 +14,7 @@ ORDER_SORTED, ORDER_REFERENCE_BUCKETS16 = 0, 1
 SYMBOLS = [
     "bbk_last_error", "bbk_version", "bbk_ctx_create", "bbk_ctx_destroy", "bbk_ctx_set_stream",
     "bbk_ctx_synchronize", "bbk_ctx_trim", "bbk_kmerset_verify_order", "bbk_kmerset_get", "bbk_ctx_profile_enable", "bbk_ctx_profile_reset", "bbk_ctx_profile_get",
-    "bbk_reads_from_ascii", "bbk_reads_from_packed", "bbk_host_alloc", "bbk_host_free", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_from_spades_binary",
+    "bbk_reads_from_ascii", "bbk_reads_from_packed", "bbk_host_alloc", "bbk_host_free", "bbk_reads_from_device", "bbk_reads_synth", "bbk_reads_synth_meta", "bbk_reads_from_spades_binary",
     "bbk_reads_write_spades_binary", "bbk_reads_count", "bbk_reads_bases",
     "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
     "bbk_count", "bbk_count_begin", "bbk_count_push_reads", "bbk_count_push_ascii", "bbk_count_finish", "bbk_count_abort",
@@ -90,6 +90,7 @@ def load_library():
     L.bbk_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.bbk_host_free.argtypes = [vp]
     L.bbk_reads_synth.argtypes = [vp, u64, u32, u64, C.c_double, u64, u64, C.POINTER(vp)]
+    L.bbk_reads_synth_meta.argtypes = [vp, u64, u32, u32, u64, u64, C.c_double, C.c_double, u64, C.POINTER(vp), vp, vp]
     L.bbk_reads_from_spades_binary.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     L.bbk_reads_write_spades_binary.argtypes = [vp, vp, C.c_char_p]
     L.bbk_reads_count.restype = u64
@@ -258,6 +259,17 @@ class Context:
         _check(self._L.bbk_reads_synth(self._h, n_reads, read_len, genome_len, sub_rate, seed_genome, seed_reads,
                                        C.byref(h)))
         return Reads(self, h)
+
+    def reads_synth_meta(self, n_reads, read_len=150, n_genomes=200, min_len=500_000, max_len=8_000_000, sigma=2.0,
+                         sub_rate=0.005, seed=44, want_community=False):
+        """Metagenome-shaped reads (SURVEY 8d / BASELINE configs[4]); want_community: also (genome lengths, abundances)."""
+        h = C.c_void_p()
+        gl = np.zeros(n_genomes, dtype=np.uint64)
+        ab = np.zeros(n_genomes, dtype=np.float64)
+        _check(self._L.bbk_reads_synth_meta(self._h, n_reads, read_len, n_genomes, min_len, max_len, sigma, sub_rate, seed,
+                                            C.byref(h), _ptr(gl), _ptr(ab)))
+        r = Reads(self, h)
+        return (r, gl, ab) if want_community else r
 
     # ---- operators -----------------------------------------------------------------------------
     def count(self, reads, k, flags=BOTH_STRANDS):

@@ -132,3 +132,31 @@ def test_two_files_and_stop(dump, tmp_path):
     b.write_text(">x\nTTTT\n")
     fast, _ = dump(["--fast", "4", "16", str(a), str(b)])
     assert fast == ["ACGT", "TTTT"]  # the truncated record ends file a only; file b is read
+
+
+def test_parsers_under_asan_ubsan(tmp_path):
+    """Host sanitizer build (AddressSanitizer + UBSan) of the serial and the parallel parser on the corner cases and on
+    tiny blocks (carry-over, chunk boundaries inside records): no report, same output."""
+    from spades_for_blackbird_amd import build_host
+    exe = build_host.build_sanitized()
+    files = {}
+    files["a.fa"] = ">r1 c\nACGT\nacgtnn\n\nGG\n>r2\nTTTT\n>empty\n>r3\nAC\n"
+    files["b.fq"] = "@a\nACGT\n+\nIIII\n@b\nGGCC\nTT\n+b\nIIII\nII\n@c\nACGTAC\n+\nIII\n@d\nAAAA\n+\nIIII\n"
+    files["c.fq"] = "@r@1\nACGTA\n+\n@IIII\n@r2\nCCCCC\n+\n>>>>>\n@r3\nGGGNGGGG\n+\n@@@@@@@@\n"
+    files["d.fa"] = ">x\r\nACGT\r\nGGCC\r\n>y\r\nTT\r\n"
+    files["e.fa"] = "garbage\n>x\nacgtNNacgtacg"
+    files["f.fq"] = "@x\nACGT\n+"
+    files["g.fa"] = ">only header"
+    rng = random.Random(3)
+    files["h.fa"] = "".join(">r%d\n%s\n" % (i, "".join(rng.choice("ACGTN") for _ in range(rng.choice([0, 1, 33, 150, 400]))))
+                            for i in range(500))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    for name, text in files.items():
+        p = tmp_path / name
+        p.write_bytes(text.encode())
+        ser = subprocess.run([exe, "--serial-lv", str(p)], capture_output=True, text=True, env=env)
+        assert ser.returncode == 0 and "Sanitizer" not in ser.stderr and "runtime error" not in ser.stderr, ser.stderr[-2000:]
+        for threads, block in ((1, 1 << 20), (4, 5), (3, 64)):
+            r = subprocess.run([exe, "--fast", str(threads), str(block), str(p)], capture_output=True, text=True, env=env)
+            assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+            assert r.stdout == ser.stdout, (name, threads, block)
