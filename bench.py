@@ -112,20 +112,40 @@ def gfa_build(ctx, reads, k):
     d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     path = os.path.join(d, "bbk_bench_%d.gfa" % os.getpid())
     best = None
-    for _ in range(2):  # first pass warms the allocator, second is reported
+    graph_fams = ["walk0", "walk1", "links", "gfa_text", "scatter", "hist", "scan"]
+
+    def snap(fams):
+        p = {f: ctx.profile_get(f) for f in fams}
+        return {f: v for f, v in p.items() if v["launches"]}
+    for it in range(2):  # first pass warms the allocator, second is reported (with HIP-event times per kernel family)
+        ctx.profile(it == 1)
+        ctx.profile_reset()
         t0 = time.perf_counter()
         x = ctx.extindex(reads, k)
         t1 = time.perf_counter()
+        prof_ext = snap(FAMILIES) if it == 1 else {}
+        ctx.profile_reset()
         u = ctx.unitigs(x)
         t2 = time.perf_counter()
+        prof_uni = snap(graph_fams) if it == 1 else {}
+        ctx.profile_reset()
         u.write_gfa(path)
         t3 = time.perf_counter()
+        prof_wr = snap(graph_fams) if it == 1 else {}
         best = {"wall_s": t3 - t0, "extindex_s": t1 - t0, "unitigs_s": t2 - t1, "write_s": t3 - t2,
                 "kmers": len(x), "unitigs": len(u), "vertices": u.n_vertices, "links": u.n_links,
-                "gfa_bytes": os.path.getsize(path), "output": "GFA1 text on tmpfs"}
+                "gfa_bytes": os.path.getsize(path), "output": "GFA1 text on tmpfs",
+                "extindex_kernel_ms": {f: v["ms"] for f, v in prof_ext.items()},
+                # the extension index is the same sort-reduce with a mask payload: roofline of its dominant kernel
+                "extindex_roofline": roofline_of(prof_ext, 1),
+                "unitigs_kernel_ms": {f: v["ms"] for f, v in prof_uni.items()},
+                "unitigs_lookup_gbs": {f: v["bytes"] / (v["ms"] * 1e-3) / 1e9 for f, v in prof_uni.items()
+                                       if v["bytes"] and v["ms"]},
+                "write_kernel_ms": {f: v["ms"] for f, v in prof_wr.items()}}
         os.unlink(path)
         u.free()
         x.free()
+    ctx.profile(False)
     return best
 
 
@@ -169,6 +189,14 @@ def e2e(ctx, reads, args):
     k = args.k
     d = tempfile.mkdtemp(prefix="bbk_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     out = {"input": None}
+    # the CLIs are separate processes on the same GPU: hand this process's cached device memory back first, or the
+    # driver has to evict it to make room for theirs (seen as a 1 s "device" phase in the child)
+    ctx.trim()
+    try:
+        import torch
+        torch.cuda.empty_cache()
+    except Exception:
+        pass
     try:
         fa = os.path.join(d, "reads.fa")
         n = write_fasta(reads, fa)

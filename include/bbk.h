@@ -257,6 +257,11 @@ int bbk_unitigs_write_fasta(bbk_ctx *ctx, const bbk_unitigs *u, const char *path
 /* FASTG as FastgWriter::WriteSegmentsAndLinks (common/io/graph/fastg_writer.cpp:20-47): every edge and its
  * conjugate, header = EDGE_<id>_length_<len>_cov_<cov>['] : successors ; */
 int bbk_unitigs_write_fastg(bbk_ctx *ctx, const bbk_unitigs *u, const char *path);
+/* SPAdes binary graph <basename>.grseq + <basename>.cvr as io::binary::BasicGraphIO<Graph>().Save
+ * (common/io/binary/basic.hpp:24-27, graph.hpp:27-46, coverage.hpp:24-29; gbuilder --spades,
+ * projects/gbuilder/main.cpp:221-222).  Edge ids 3+2i as in the GFA; vertex ids in ascending end-k-mer order (the
+ * reference's follow its BooPHF indices; its loader takes any consistent numbering). */
+int bbk_unitigs_write_spades(bbk_ctx *ctx, const bbk_unitigs *u, const char *basename);
 void bbk_unitigs_free(bbk_unitigs *u);
 
 #ifdef __cplusplus

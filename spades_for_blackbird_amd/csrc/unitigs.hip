@@ -308,7 +308,10 @@ static void run_walk(bbk_ctx *ctx, int pass, const bbk_extindex *x, const uint64
     if (E == 0) return;
     const int w0bits = (x->W == 1) ? (int)(2 * x->k) : 64;
     const int pshift = w0bits - (int)x->prefix_bits;
-    KernelTimer t(ctx, pass == 0 ? "walk0" : "walk1", 0);
+    // bytes: every non-junction k-mer is stepped over once per orientation; a step is one lookup = 2 prefix-table
+    // entries + ~3 key probes + 1 mask byte (latency-bound pointer chase: the figure is for reading the rate, not a
+    // roofline claim); pass 1 also writes the bases
+    KernelTimer t(ctx, pass == 0 ? "walk0" : "walk1", 2.0 * (double)x->n * (3.0 * x->W * 8 + 8 + 1));
     if (pass == 0)
         hipLaunchKernelGGL((k_walk<W, 0>), dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ctx->stream,
                            x->keys.as<Key<W>>(), x->masks.as<uint8_t>(), x->prefix.as<uint32_t>(), pshift, x->n,
@@ -1180,6 +1183,134 @@ int bbk_unitigs_write_fasta(bbk_ctx *ctx, const bbk_unitigs *u, const char *path
         }
         const int cl = fclose(f);
         BBK_REQUIRE(ok && cl == 0, BBK_ERR_IO, "short write to %s", path);
+    });
+}
+
+// SPAdes binary graph: <basename>.grseq (io::binary::GraphIO::SaveImpl, common/io/binary/graph.hpp:27-46) +
+// <basename>.cvr (BaseCoverageIO::SaveImpl, common/io/binary/coverage.hpp:24-29), what `spades-gbuilder --spades`
+// writes through BasicGraphIO::Save (common/io/binary/basic.hpp:24-27, projects/gbuilder/main.cpp:221-222).
+//   .grseq: u64 vreserved, u64 ereserved, u64 vertex_count; per vertex (id order): u64 id, u64 conjugate id, then per
+//           outgoing edge e1 with conj(e1) >= e1: u64 e1, u64 e2 = conj(e1), u64 EdgeEnd(e1), u64 EdgeStart(e2),
+//           Sequence (u64 length + ceil(length/32) u64 words, 2 bits per base, Sequence::BinWrite
+//           common/sequence/sequence.hpp:431-442); u64 0 ends the vertex.
+//   .cvr:   per canonical edge u64 id, u32 raw coverage; u64 0 at the end.
+// Ids: edge i (GFA segment 3+2i) and its conjugate 3+2i+1 (a self-conjugate edge is its own), as
+// FastGraphFromSequencesConstructor numbers them (debruijn_graph_constructor.hpp:450-465, graph_core.hpp:228,610-624).
+// Vertices: one pair per distinct canonical end k-mer, numbered 3+2j / 3+2j+1 in ascending k-mer order -- the
+// reference numbers them in BooPHF-index order (:494-515), which no other implementation can reproduce, and its
+// loader (LoadImpl :48-96) accepts any consistent numbering; parity is therefore structural (tests rebuild the graph
+// from the file and compare it with the GFA).
+static void write_spades_graph(bbk_ctx *ctx, const bbk_unitigs *u, const char *basename) {
+    ensure_host(ctx, u);
+    const unsigned k = u->k;
+    const uint64_t nu = u->n;
+    const int W = (int)words_of(k);
+    // end k-mers of every edge in canonical form
+    struct End {
+        uint64_t w[4];
+        uint32_t edge;
+        uint8_t is_end, is_rc;
+    };
+    std::vector<End> ends(2 * nu);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+    for (uint64_t i = 0; i < nu; ++i) {
+        const char *s = u->bases.data() + u->offsets[i];
+        const uint64_t len = u->offsets[i + 1] - u->offsets[i];
+        for (int e = 0; e < 2; ++e) {
+            const std::string km(s + (e ? len - k : 0), k);
+            const std::string r = str_rc(km);
+            const bool minimal = km <= r;  // IsMinimal: base-lexicographic, ties minimal (rtseq.hpp:407-415)
+            End &d = ends[2 * i + e];
+            memset(d.w, 0, sizeof(d.w));
+            pack_kmer((minimal ? km : r).data(), (int)k, d.w, W);
+            d.edge = (uint32_t)i;
+            d.is_end = (uint8_t)e;
+            d.is_rc = minimal ? 0 : 1;
+        }
+    }
+    std::vector<uint32_t> order(2 * nu);
+    for (uint64_t i = 0; i < 2 * nu; ++i) order[i] = (uint32_t)i;
+    auto less = [&](uint32_t a, uint32_t b) {
+        for (int w = 0; w < W; ++w)
+            if (ends[a].w[w] != ends[b].w[w]) return ends[a].w[w] < ends[b].w[w];
+        return a < b;
+    };
+    std::sort(order.begin(), order.end(), less);
+    // vertex pair j for every end; vid(end) = 3 + 2j + (k-mer is the reverse complement of the canonical form)
+    std::vector<uint64_t> vid(2 * nu);
+    uint64_t nv = 0;
+    for (uint64_t r = 0; r < 2 * nu; ++r) {
+        const uint32_t a = order[r];
+        if (r > 0) {
+            const uint32_t p = order[r - 1];
+            bool same = true;
+            for (int w = 0; w < W; ++w) same = same && ends[a].w[w] == ends[p].w[w];
+            if (!same) ++nv;
+        }
+        vid[a] = 3 + 2 * nv + ends[a].is_rc;
+    }
+    if (nu) ++nv;
+    auto conj_v = [](uint64_t v) { return ((v - 3) ^ 1ull) + 3; };
+    // outgoing lists: edge i (stored orientation) leaves vid(start of i)
+    std::vector<std::vector<uint32_t>> out_of(2 * nv);
+    for (uint64_t i = 0; i < nu; ++i) out_of[vid[2 * i] - 3].push_back((uint32_t)i);
+    const std::string gpath = std::string(basename) + ".grseq", cpath = std::string(basename) + ".cvr";
+    FILE *f = fopen(gpath.c_str(), "wb");
+    BBK_REQUIRE(f != nullptr, BBK_ERR_IO, "cannot open %s for writing", gpath.c_str());
+    bool ok = true;
+    auto put64 = [&](uint64_t v) { ok = ok && fwrite(&v, 8, 1, f) == 1; };
+    put64(3 + 2 * nv);  // reserved id ranges: every id handed out is below
+    put64(3 + 2 * nu);
+    put64(2 * nv);
+    std::vector<uint64_t> words;
+    for (uint64_t v = 0; v < 2 * nv && ok; ++v) {
+        put64(3 + v);
+        put64(conj_v(3 + v));
+        for (uint32_t i : out_of[v]) {
+            const char *s = u->bases.data() + u->offsets[i];
+            const uint64_t len = u->offsets[i + 1] - u->offsets[i];
+            // self-conjugate edge: s == rc(s), its conjugate is itself
+            bool selfc = true;
+            for (uint64_t a = 0; a < len && selfc; ++a) {
+                const char c = s[len - 1 - a];
+                selfc = s[a] == (c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A');
+            }
+            const uint64_t e1 = 3 + 2 * (uint64_t)i, e2 = selfc ? e1 : e1 + 1;
+            put64(e1);
+            put64(e2);
+            put64(vid[2 * i + 1]);          // EdgeEnd(e1)
+            put64(conj_v(vid[2 * i + 1]));  // EdgeStart(conj e1) = conjugate of EdgeEnd(e1)
+            put64(len);
+            words.assign((len + 31) / 32, 0);
+            for (uint64_t a = 0; a < len; ++a) {
+                const uint64_t c = s[a] == 'A' ? 0 : s[a] == 'C' ? 1 : s[a] == 'G' ? 2 : 3;
+                words[a >> 5] |= c << ((a & 31) << 1);
+            }
+            ok = ok && (words.empty() || fwrite(words.data(), 8, words.size(), f) == words.size());
+        }
+        put64(0);
+    }
+    const int cl = fclose(f);
+    BBK_REQUIRE(ok && cl == 0, BBK_ERR_IO, "short write to %s", gpath.c_str());
+    f = fopen(cpath.c_str(), "wb");
+    BBK_REQUIRE(f != nullptr, BBK_ERR_IO, "cannot open %s for writing", cpath.c_str());
+    ok = true;
+    for (uint64_t i = 0; i < nu && ok; ++i) {
+        const uint64_t e1 = 3 + 2 * i;
+        const uint64_t raw = u->has_cov ? u->kc[i] : 0;
+        const uint32_t cov = raw > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)raw;
+        ok = fwrite(&e1, 8, 1, f) == 1 && fwrite(&cov, 4, 1, f) == 1;
+    }
+    const uint64_t zero = 0;
+    ok = ok && fwrite(&zero, 8, 1, f) == 1;
+    const int cl2 = fclose(f);
+    BBK_REQUIRE(ok && cl2 == 0, BBK_ERR_IO, "short write to %s", cpath.c_str());
+}
+
+int bbk_unitigs_write_spades(bbk_ctx *ctx, const bbk_unitigs *u, const char *basename) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && u && basename, BBK_ERR_ARG, "bbk_unitigs_write_spades: NULL argument");
+        write_spades_graph(ctx, u, basename);
     });
 }
 

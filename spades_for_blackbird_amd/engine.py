@@ -25,7 +25,7 @@ SYMBOLS = [
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_clip_tips", "bbk_extindex_free",
     "bbk_unitigs_build", "bbk_unitigs_add_coverage", "bbk_unitigs_add_coverage_counts", "bbk_unitigs_export_kc", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
     "bbk_unitigs_vertices", "bbk_unitigs_links", "bbk_unitigs_export", "bbk_unitigs_export_links",
-    "bbk_unitigs_write_gfa", "bbk_unitigs_write_fasta", "bbk_unitigs_write_fastg", "bbk_unitigs_free",
+    "bbk_unitigs_write_gfa", "bbk_unitigs_write_fasta", "bbk_unitigs_write_fastg", "bbk_unitigs_write_spades", "bbk_unitigs_free",
 ]
 
 
@@ -154,6 +154,7 @@ def load_library():
         L.bbk_unitigs_write_gfa.argtypes = [vp, vp, C.c_char_p]
         L.bbk_unitigs_write_fasta.argtypes = [vp, vp, C.c_char_p]
         L.bbk_unitigs_write_fastg.argtypes = [vp, vp, C.c_char_p]
+        L.bbk_unitigs_write_spades.argtypes = [vp, vp, C.c_char_p]
         L.bbk_unitigs_free.argtypes = [vp]
     _LIB = L
     return L
@@ -596,3 +597,7 @@ class Unitigs(_Handle):
 
     def write_fasta(self, path):
         _check(self._L.bbk_unitigs_write_fasta(self.ctx._h, self._h, path.encode()))
+
+    def write_spades(self, basename):
+        """<basename>.grseq + <basename>.cvr (the SPAdes binary graph of gbuilder --spades)"""
+        _check(self._L.bbk_unitigs_write_spades(self.ctx._h, self._h, basename.encode()))

@@ -6,7 +6,7 @@
 // -t = parser threads, -b = bytes of input text per block: the reads are streamed block by block through
 // bbk_extindex_begin / push / finish (and, with -c, a (k+1)-mer counter), so host and device memory are bounded as in
 // the reference (binary read chunks + bounded sort buffers); -tmp-dir is accepted (there are no temp files).
-// --spades (binary graph) is a SURVEY 8(f) "next" row and is refused with a clear message.
+// --spades writes <output>.grseq + <output>.cvr (io::binary::BasicGraphIO::Save, :221-222).
 #include <cstring>
 #include <string>
 #include <vector>
@@ -74,8 +74,6 @@ int main(int argc, char **argv) {
         case GFA: info("Producing graph in GFA1 format"); break;
         case SPADES: info("Producing graph in SPAdes internal format"); break;
     }
-    if (mode == SPADES)
-        fatal("this build writes --unitigs, --gfa and --fastg; the SPAdes-binary graph format is not implemented yet");
     if (coverage && mode == UNITIGS) info("Note: -c has no effect on --unitigs output");
 
     // LoadDataset (:89-101)
@@ -143,7 +141,8 @@ int main(int argc, char **argv) {
         info("Saving graph to %s", outfile.c_str());
         t0 = now_s();
         if (mode == GFA) check(bbk_unitigs_write_gfa(ctx, u, outfile.c_str()), "bbk_unitigs_write_gfa");
-        else check(bbk_unitigs_write_fastg(ctx, u, outfile.c_str()), "bbk_unitigs_write_fastg");
+        else if (mode == FASTG) check(bbk_unitigs_write_fastg(ctx, u, outfile.c_str()), "bbk_unitigs_write_fastg");
+        else check(bbk_unitigs_write_spades(ctx, u, outfile.c_str()), "bbk_unitigs_write_spades");  // <out>.grseq + .cvr
         ph.write = now_s() - t0;
     }
     bbk_unitigs_free(u);

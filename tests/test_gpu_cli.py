@@ -90,3 +90,37 @@ def test_kmer_estimating_cli_toy(bins, golden, golden_dir, tmp_path):
 
 def rcs(s):
     return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def test_cli_streaming_blocks_and_modes(bins, golden, golden_dir, tmp_path):
+    """The CLIs stream their input block by block (-b = bytes of input text per block, -t = parser threads): tiny blocks
+    (dozens of pushes + merges) must give the same final_kmers and the same GFA as one block; -c and --spades go through
+    the streaming path too (coverage from a (k+1)-mer counter fed by the same blocks)."""
+    g = golden["toy_kmercount"]
+    files = [os.path.join(golden_dir, f) for f in g["files"]]
+    for b in ("20000", "536870912"):
+        wd = tmp_path / ("w" + b)
+        r = subprocess.run([bins["spades-kmercount"], "-k", "21", "-t", "3", "-b", b, "-w", str(wd)] + files,
+                           capture_output=True, text=True, env=dict(os.environ, BBK_MERGE_MIN="0", BBK_PHASES="1"))
+        assert r.returncode == 0, r.stderr
+        assert hashlib.md5(open(wd / "final_kmers", "rb").read()).hexdigest() == g["k21"]["md5"]
+        ph = [l for l in r.stdout.splitlines() if l.startswith("BBK_PHASES ")]
+        import json
+        nblocks = json.loads(ph[0][len("BBK_PHASES "):])["blocks"]
+        assert (nblocks == len(files)) if b != "20000" else (nblocks > 2 * len(files))  # one block per file, or many
+    gg = golden["toy_gbuilder"]
+    f = os.path.join(golden_dir, gg["file"])
+    texts = []
+    for b in ("15000", "536870912"):
+        out = tmp_path / ("c%s.gfa" % b)
+        r = subprocess.run([bins["spades-gbuilder"], f, str(out), "-k", "21", "--gfa", "-c", "-b", b, "-t", "2"],
+                           capture_output=True, text=True, env=dict(os.environ, BBK_MERGE_MIN="0"))
+        assert r.returncode == 0, r.stderr
+        texts.append(open(out).read())
+    assert gfa_canon.canon_text(texts[0], 21, with_kc=True) == gfa_canon.canon_text(texts[1], 21, with_kc=True)
+    kcs = sorted(int(t[5:]) for l in texts[0].splitlines() if l.startswith("S") for t in l.split("\t") if t.startswith("KC:i:"))
+    assert kcs == sorted(gg["k21"]["KC"])
+    base = tmp_path / "bin_graph"
+    r = subprocess.run([bins["spades-gbuilder"], f, str(base), "-k", "21", "--spades", "-c"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(str(base) + ".grseq") > 24 and os.path.getsize(str(base) + ".cvr") == 12 * gg["k21"]["n_unitigs"] + 8

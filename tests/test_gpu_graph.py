@@ -341,3 +341,101 @@ def test_full_size_graph_properties(k, n_reads):
     total = int(kc.sum())
     assert inst <= total < inst * (1 + 1e-5)           # self-conjugate unitigs count their instances on both strands
     ctx.close()
+
+
+def _load_grseq(path):
+    """io::binary::GraphIO::LoadImpl (common/io/binary/graph.hpp:48-96) restated: returns (vertices {id: conj id},
+    edges {id: (conj id, start vertex, end vertex, sequence)})."""
+    import struct
+    data = open(path, "rb").read()
+    pos = 0
+
+    def u64():
+        nonlocal pos
+        v = struct.unpack_from("<Q", data, pos)[0]
+        pos += 8
+        return v
+    vres, eres, nvert = u64(), u64(), u64()
+    verts, edges = {}, {}
+    for _ in range(nvert):
+        v, cv = u64(), u64()
+        verts[v] = cv
+        while True:
+            e1 = u64()
+            if e1 == 0:
+                break
+            e2, end1, start2, size = u64(), u64(), u64(), u64()
+            nw = (size + 31) // 32
+            words = struct.unpack_from("<%dQ" % nw, data, pos)
+            pos += 8 * nw
+            seq = "".join("ACGT"[(words[i >> 5] >> ((i & 31) << 1)) & 3] for i in range(size))
+            edges[e1] = (e2, v, end1, seq)
+            assert verts.get(v) == cv and start2 < vres and end1 < vres and e1 < eres and e2 < eres
+    assert pos == len(data)
+    return verts, edges
+
+
+@pytest.mark.parametrize("k,seed", [(21, 3), (33, 5), (5, 1)])
+def test_spades_binary_graph(ctx, k, seed, tmp_path):
+    """gbuilder --spades: <out>.grseq + <out>.cvr.  No reference file exists to compare bytes with and the reference's
+    vertex numbering follows BooPHF indices ("parity unpinned"): the file is read back the way the reference's loader
+    reads it and the graph it describes must be the graph of the GFA -- same edges under the same ids, a vertex per
+    oriented junction k-mer, the same links, the same coverage."""
+    import struct
+    reads = synth_reads(1500, read_len=100, genome_len=4000 if k > 9 else 600, sub_rate=0.01, seed=seed)
+    r = ctx.reads_from_ascii(reads)
+    x = ctx.extindex(r, k)
+    u = ctx.unitigs(x)
+    u.add_coverage(r)
+    base = str(tmp_path / "g")
+    u.write_spades(base)
+    verts, edges = _load_grseq(base + ".grseq")
+    seqs = u.sequences()
+    assert sorted(edges) == [3 + 2 * i for i in range(len(seqs))]
+    vk = {}  # vertex id -> oriented k-mer
+
+    def bind(v, kmer):
+        assert vk.setdefault(v, kmer) == kmer, "vertex %d stands for two k-mers" % v
+    for i, s in enumerate(seqs):
+        e2, vs, ve, seq = edges[3 + 2 * i]
+        assert seq == s
+        assert e2 == (3 + 2 * i if s == rc(s) else 3 + 2 * i + 1)
+        bind(vs, s[:k])
+        bind(ve, s[-k:])
+        bind(verts[vs], rc(s[:k]))
+        bind(verts[ve], rc(s[-k:]))
+    assert len(set(vk.values())) == len(vk)                       # one vertex per oriented k-mer
+    assert all(verts[verts[v]] == v and verts[v] != v for v in verts)
+    assert len(verts) == 2 * u.n_vertices and set(vk) == set(verts)
+    # the graph the file describes, written the way GFAWriter::WriteSegmentsAndLinks walks a graph
+    # (io/graph/gfa_writer.cpp:35-52: for every canonical vertex, every incoming x outgoing oriented edge; '+' iff the
+    # oriented edge is the canonical one), must be the GFA of the same unitigs in canonical form
+    conj_e = {}
+    start_of, end_of = {}, {}
+    for e1, (e2, vs, ve, seq) in edges.items():
+        conj_e[e1], conj_e[e2] = e2, e1
+        start_of[e1], end_of[e1] = vs, ve
+        start_of[e2], end_of[e2] = verts[ve], verts[vs]
+    out_e, in_e = {}, {}
+    for e in start_of:
+        out_e.setdefault(start_of[e], []).append(e)
+        in_e.setdefault(end_of[e], []).append(e)
+    lines = ["S\t%d\t%s\tDP:f:0\tKC:i:0" % (3 + 2 * i, sq) for i, sq in enumerate(seqs)]
+    for v in sorted(verts):
+        if v > verts[v]:
+            continue
+        for a in sorted(in_e.get(v, [])):
+            for b in sorted(out_e.get(v, [])):
+                lines.append("L\t%d\t%s\t%d\t%s\t%dM" % (min(a, conj_e[a]), "+" if a <= conj_e[a] else "-",
+                                                          min(b, conj_e[b]), "+" if b <= conj_e[b] else "-", k))
+    gfa_path = str(tmp_path / "g.gfa")
+    u.write_gfa(gfa_path)
+    assert gfa_canon.canon_text("\n".join(lines) + "\n", k) == gfa_canon.canon_text(open(gfa_path).read(), k)
+    # coverage file: (edge id, raw coverage) per canonical edge, zero-terminated
+    cv = open(base + ".cvr", "rb").read()
+    kc = u.kc()
+    assert len(cv) == 12 * len(seqs) + 8
+    for i in range(len(seqs)):
+        e, c = struct.unpack_from("<QI", cv, 12 * i)
+        assert e == 3 + 2 * i and c == kc[i]
+    assert struct.unpack_from("<Q", cv, 12 * len(seqs))[0] == 0
