@@ -36,16 +36,21 @@ inline bool ends_with(const std::string &s, const std::string &suf) {
     return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
 }
 
-// Returns every read file of every library, in library order (left, right, interlaced, merged, single).
-inline bool load_dataset_yaml(const std::string &path, std::vector<std::string> &files, std::string &err) {
+// one library: its read files by kind, plus the two scalar keys that are passed through to an output dataset
+struct DatasetLib {
+    std::vector<std::string> v[5];  // left, right, interlaced, merged, single
+    std::string type, orientation;
+};
+enum { LIB_LEFT = 0, LIB_RIGHT = 1, LIB_INTERLACED = 2, LIB_MERGED = 3, LIB_SINGLE = 4 };
+
+inline bool load_dataset_libs(const std::string &path, std::vector<DatasetLib> &libs, std::string &err) {
     std::ifstream in(path);
     if (!in) {
         err = "cannot open dataset file " + path;
         return false;
     }
     const std::string dir = dirname_of(path);
-    struct Lib { std::vector<std::string> v[5]; };
-    std::vector<Lib> libs;
+    typedef DatasetLib Lib;
     static const char *keys[5] = {"left reads", "right reads", "interlaced reads", "merged reads", "single reads"};
     int cur_key = -1;
     std::string line;
@@ -80,7 +85,11 @@ inline bool load_dataset_yaml(const std::string &path, std::vector<std::string> 
         cur_key = -1;
         for (int i = 0; i < 5; ++i)
             if (key == keys[i]) cur_key = i;
-        if (cur_key < 0) continue;  // type / orientation / number: not needed on this path
+        if (cur_key < 0) {  // type / orientation are kept for the output dataset; the rest is not needed on this path
+            if (key == "type") libs.back().type = unquote(val);
+            if (key == "orientation") libs.back().orientation = unquote(val);
+            continue;
+        }
         if (!val.empty() && val[0] == '[') {
             size_t e = val.find(']');
             std::string inner = val.substr(1, e == std::string::npos ? std::string::npos : e - 1);
@@ -93,14 +102,47 @@ inline bool load_dataset_yaml(const std::string &path, std::vector<std::string> 
             cur_key = -1;
         }
     }
+    size_t n = 0;
     for (const Lib &l : libs)
-        for (int i = 0; i < 5; ++i)
-            for (const std::string &f : l.v[i]) files.push_back(f);
-    if (files.empty()) {
+        for (int i = 0; i < 5; ++i) n += l.v[i].size();
+    if (n == 0) {
         err = "no read files found in " + path;
         return false;
     }
     return true;
+}
+
+// Returns every read file of every library, in library order (left, right, interlaced, merged, single).
+inline bool load_dataset_yaml(const std::string &path, std::vector<std::string> &files, std::string &err) {
+    std::vector<DatasetLib> libs;
+    if (!load_dataset_libs(path, libs, err)) return false;
+    for (const DatasetLib &l : libs)
+        for (int i = 0; i < 5; ++i)
+            for (const std::string &f : l.v[i]) files.push_back(f);
+    return true;
+}
+
+// Writes a dataset description with the keys of SequencingLibraryBase::yamlize (common/pipeline/library.cpp:78-87).
+inline bool save_dataset_yaml(const std::string &path, const std::vector<DatasetLib> &libs) {
+    std::ofstream out(path);
+    if (!out) return false;
+    static const char *keys[5] = {"left reads", "right reads", "interlaced reads", "merged reads", "single reads"};
+    for (const DatasetLib &l : libs) {
+        bool first = true;
+        auto lead = [&]() -> const char * {
+            const char *p = first ? "- " : "  ";
+            first = false;
+            return p;
+        };
+        if (!l.orientation.empty()) out << lead() << "orientation: \"" << l.orientation << "\"\n";
+        if (!l.type.empty()) out << lead() << "type: \"" << l.type << "\"\n";
+        for (int i = 0; i < 5; ++i) {
+            if (l.v[i].empty()) continue;
+            out << lead() << keys[i] << ":\n";
+            for (const std::string &f : l.v[i]) out << "    - \"" << f << "\"\n";
+        }
+    }
+    return (bool)out;
 }
 
 }  // namespace bbkhost

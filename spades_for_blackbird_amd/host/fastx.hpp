@@ -48,6 +48,23 @@ class FastxReader {
         return got;
     }
 
+    // One record with its name and quality (what spades-read-filter passes through): name = the header line without
+    // its first character (kseq reads the name up to the end of the line here, KS_SEP_LINE, kseq.h:182), seq = the
+    // upper-cased sequence, qual = the quality string ("" for FASTA).  false at the end of the stream.
+    bool next_record(std::string &name, std::string &seq, std::string &qual) {
+        if (eof_) return false;
+        keep_meta_ = true;
+        seq.clear();
+        name_.clear();
+        qual_.clear();
+        const bool ok = next(seq);
+        keep_meta_ = false;
+        if (!ok) return false;
+        name.swap(name_);
+        qual.swap(qual_);
+        return true;
+    }
+
   private:
     int getc_() {
         if (pos_ >= len_) {
@@ -88,10 +105,11 @@ class FastxReader {
             if (c == -1) { eof_ = true; return false; }
             last_char_ = c;
         }
-        if (!getline_(nullptr)) {  // name + comment; a header character that is the last byte: end of file (kseq.h:182)
-            eof_ = true;
+        if (!getline_(keep_meta_ ? &name_ : nullptr)) {  // name + comment; a header character that is the last byte:
+            eof_ = true;                                 // end of file (kseq.h:182)
             return false;
         }
+        if (keep_meta_) strip_cr_(name_, 0);
         const size_t start = out.size();
         // sequence lines
         while ((c = getc_()) != -1 && c != '>' && c != '+' && c != '@') {
@@ -125,6 +143,7 @@ class FastxReader {
             strip_cr_(q, 0);
         } while (q.size() < seq_len);
         const size_t qlen = q.size();
+        if (keep_meta_) qual_ = q;
         last_char_ = 0;
         if (qlen != seq_len) {  // truncated quality string: the reference stops here
             out.resize(start);
@@ -138,7 +157,8 @@ class FastxReader {
     gzFile fp_ = nullptr;
     char buf_[1 << 16];
     int pos_ = 0, len_ = 0;
-    bool eof_in_ = false, eof_ = false, hit_nl_ = false;
+    bool eof_in_ = false, eof_ = false, hit_nl_ = false, keep_meta_ = false;
+    std::string name_, qual_;
     int last_char_ = 0;
 };
 

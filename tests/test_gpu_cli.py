@@ -124,3 +124,83 @@ def test_cli_streaming_blocks_and_modes(bins, golden, golden_dir, tmp_path):
     r = subprocess.run([bins["spades-gbuilder"], f, str(base), "-k", "21", "--spades", "-c"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert os.path.getsize(str(base) + ".grseq") > 24 and os.path.getsize(str(base) + ".cvr") == 12 * gg["k21"]["n_unitigs"] + 8
+
+
+def test_read_filter_cli(bins, golden, golden_dir, tmp_path):
+    """spades-read-filter drop-in (projects/kmercount/read_filter.cpp): reads whose median k-mer multiplicity is <= -c
+    are dropped, a pair stays when either mate passes; names and qualities pass through.  The reference's
+    multiplicities are approximate (counting quotient filter), the engine's exact: the expectation is computed from the
+    oracle's exact canonical counts with the reference's own median rule (CountMedianMlt,
+    io/reads/coverage_filtering_read_wrapper.hpp:36-50: the element at index size/2 of the sorted multiplicities)."""
+    import gzip
+    import re
+    import numpy as np
+    g = golden["toy_kmercount"]
+    f1, f2 = [os.path.join(golden_dir, f) for f in g["files"]]
+    k, thr = 21, 20
+
+    def records(path):
+        out = []
+        with gzip.open(path, "rt") as f:
+            while True:
+                h = f.readline()
+                if not h:
+                    break
+                s = f.readline().rstrip("\n")
+                f.readline()
+                q = f.readline().rstrip("\n")
+                out.append((h.rstrip("\n")[1:], s, q))
+        return out
+    r1, r2 = records(f1), records(f2)
+    # a third, single-end library: a few reads of r1 plus junk that never repeats
+    single = tmp_path / "single.fq"
+    rng = np.random.default_rng(3)
+    with open(single, "w") as f:
+        for n, s, q in r1[:50]:
+            f.write("@%s\n%s\n+\n%s\n" % (n, s, q))
+        for j in range(20):
+            s = "".join("ACGT"[i] for i in rng.integers(0, 4, size=100))
+            f.write("@junk%d\n%s\n+\n%s\n" % (j, s, "I" * 100))
+    y = tmp_path / "ds.yaml"
+    y.write_text("- left reads: [%s]\n  orientation: fr\n  right reads: [%s]\n  type: paired-end\n"
+                 "- single reads: [%s]\n  type: single\n" % (f1, f2, single))
+    out = tmp_path / "out"
+    r = subprocess.run([bins["spades-read-filter"], "-k", str(k), "-c", str(thr), "-d", str(y), "-o", str(out), "-t", "4"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # expectation from exact canonical multiplicities
+    sing = [l for l in open(single).read().split("\n")]
+    srecs = [(sing[i][1:], sing[i + 1], sing[i + 3]) for i in range(0, len(sing) - 1, 4)]
+    allseq = [s for _, s, _ in r1 + r2 + srecs]
+    both, cnt = O.kmercount(allseq, k, 16, 2, with_counts=True)
+    mult = {}
+    for row, c in zip(both.tolist(), cnt.tolist()):
+        s = "".join("ACGT"[(row[i // 32] >> (2 * (i % 32))) & 3] for i in range(k))
+        mult[min(s, rcs(s))] = c if s != rcs(s) else c // 2   # both-strand counts: a k-mer and its RC share the count
+    def passes(seq):
+        runs = re.findall("[ACGT]+", seq.upper())
+        run = max(runs, key=len) if runs else ""
+        if len(run) < k:
+            return 0 >= thr + 1
+        ms = sorted(mult[min(run[i:i + k], rcs(run[i:i + k]))] for i in range(len(run) - k + 1))
+        return ms[len(ms) // 2] >= thr + 1
+    keep_pairs = [i for i in range(len(r1)) if passes(r1[i][1]) or passes(r2[i][1])]
+    keep_single = [i for i in range(len(srecs)) if passes(srecs[i][1])]
+    assert 0 < len(keep_pairs) <= len(r1) and 0 < len(keep_single) < len(srecs)   # the threshold really splits the data
+    def fq(recs, idx):
+        return "".join("@%s\n%s\n+\n%s\n" % recs[i] for i in idx)
+    assert open(out / "1.1.fastq").read() == fq(r1, keep_pairs)
+    assert open(out / "1.2.fastq").read() == fq(r2, keep_pairs)
+    assert open(out / "2.s.fastq").read() == fq(srecs, keep_single)
+    assert "Total %d reads processed, %d reads left after filtering" % (len(r1), len(keep_pairs)) in r.stdout
+    ds = open(out / "dataset.yaml").read()
+    assert "1.1.fastq" in ds and "1.2.fastq" in ds and "2.s.fastq" in ds and "paired-end" in ds
+    # the written dataset is readable by the tools again; --drop-quality writes FASTA
+    out2 = tmp_path / "out2"
+    r = subprocess.run([bins["spades-read-filter"], "-k", str(k), "-c", str(thr), "-d", str(out / "dataset.yaml"), "-o",
+                        str(out2), "--drop-quality"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    fa = open(out2 / "1.1.fasta").read()
+    assert fa.startswith(">" + r1[keep_pairs[0]][0] + "\n") and "+" not in fa.split("\n")[2]
+    r = subprocess.run([bins["spades-read-filter"], "-k", "21"], capture_output=True, text=True)
+    assert r.returncode == 1 and "SYNOPSIS" in r.stdout  # -d is required
