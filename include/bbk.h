@@ -48,7 +48,9 @@ int bbk_ctx_destroy(bbk_ctx *ctx);
 /* Run all kernels of this context on an existing hipStream_t (e.g. torch's current stream). */
 int bbk_ctx_set_stream(bbk_ctx *ctx, void *hip_stream);
 int bbk_ctx_synchronize(bbk_ctx *ctx);
-/* Returns the device memory this context's caching allocator holds (released blocks kept for reuse) to the driver. */
+/* Returns device memory the allocator holds but does not use to the driver -- where that is safe: the block-cache
+ * allocator (BBK_NO_VMM=1) frees its cached blocks; the default arena allocator keeps its mapped high-water mark for the
+ * life of the process (unmapping and re-mapping chunks faults on this platform, see primitives.hip). */
 int bbk_ctx_trim(bbk_ctx *ctx);
 /* Accumulated HIP-event time (ms) and launch count of one named kernel family since the last
  * reset ("extract", "hist", "scan", "scatter", "unique", "expand", "mask", "walk", ...).

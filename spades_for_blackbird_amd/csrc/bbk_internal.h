@@ -61,6 +61,7 @@ int guarded(F &&f) {
 void *pool_alloc(size_t bytes, size_t *granted, int *device);  // on the current device
 void pool_free(void *p, size_t bytes, int device);
 void pool_trim(int device);  // hipFree what this (device, host thread) has cached
+void pool_report();          // allocator statistics to stderr
 
 // Owning device buffer.
 struct DevBuf {

@@ -101,6 +101,7 @@ struct PartLevel {
     uint32_t sel_lo;
     uint32_t sel_span;
     int sel_shl;
+    uint32_t sel_mul;  // stretches (p - sel_lo) << sel_shl, which only reaches span << shl, over the whole 32 bits
     // slot mode (histogram-free HASH path): bin g of this level owns the fixed range [g*slot_cap, (g+1)*slot_cap) of
     // the output and `cursor[g]` starts at g*slot_cap; records that do not fit are appended to the spill list
     uint32_t slot_cap;     // 0: dense layout from an exact histogram
@@ -148,7 +149,10 @@ __device__ inline bool select_prefix(uint32_t &p, const PartLevel &L) {
     if (L.sel_span == 0) return true;
     const uint32_t d = p - L.sel_lo;
     if (d >= L.sel_span) return false;
+    // a span that is not a power of two would leave the top of the prefix space (up to half of the bins) empty and
+    // crowd the rest: scale by 2^32 / (span << shl) in (1, 2], monotone (bucket order = prefix order is kept)
     p = d << L.sel_shl;
+    p += __umulhi(p, L.sel_mul);
     return true;
 }
 
@@ -2449,7 +2453,14 @@ struct MsdRunner {
     struct Sel {
         uint32_t lo = 0, span = 0;
         int shl = 0;
+        uint32_t mul = 0;
         uint64_t est = 0;
+        // shl and mul from span: (d << shl) + mulhi(d << shl, mul) maps [0, span) monotonically onto [0, 2^32)
+        void finish() {
+            shl = __builtin_clz(span - 1u);
+            const uint64_t S = (uint64_t)span << shl;  // in (2^31, 2^32]
+            mul = S >= (1ull << 32) ? 0u : (uint32_t)((((1ull << 32) - S) << 32) / S);
+        }
     };
     // Where the dense result of an exact-mode pass goes when the caller has already allocated it (range passes
     // write one after the other into the final array: no concatenation copy of a 100 GB result).
@@ -2549,7 +2560,7 @@ struct MsdRunner {
             if (verbose) fprintf(stderr, "[bbk] msd declines: N=%llu needs more than two levels\n", (unsigned long long)N);
             return 0;
         }
-        PartLevel L1{1, b1, nb1, dmode, w0bits, nullptr, nullptr, sel.lo, sel.span, sel.shl};
+        PartLevel L1{1, b1, nb1, dmode, w0bits, nullptr, nullptr, sel.lo, sel.span, sel.shl, sel.mul};
 
         // level-1 tiles cover the whole instance space; a range pass keeps its share of every tile.  Reads:
         // a tile is `threads` chunks, so the histogram (512 threads) and the scatter (1024) have their own tables
@@ -2728,7 +2739,7 @@ struct MsdRunner {
         BBK_HIP(hipMemcpyAsync(seg_nb2.p, snb2.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(seg_bin.p, sbin.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(seg_size.p, h1.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
-        PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), sel.lo, sel.span, sel.shl};
+        PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), sel.lo, sel.span, sel.shl, sel.mul};
         const uint32_t ntiles2 = tstart[nb1];
         TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), seg_size.as<uint32_t>(), nb1, N, ntiles2, 1, nullptr, 0, 0};
         DevBuf desc2((size_t)ntiles2 * sizeof(uint4) + 16);
@@ -3153,7 +3164,7 @@ struct MsdRunner {
         const int w0bits = (W == 1) ? (int)(2 * k) : 64;
         DevBuf h((size_t)nb * 4 + 16);
         BBK_HIP(hipMemsetAsync(h.p, 0, (size_t)nb * 4 + 16, ctx->stream));
-        PartLevel L{1, bits, nb, dmode, w0bits, nullptr, nullptr, 0u, 0u, 0};
+        PartLevel L{1, bits, nb, dmode, w0bits, nullptr, nullptr, 0u, 0u, 0, 0u};
         TileMap M{nullptr, nullptr, nullptr, 1, n_records, 0, 1, nullptr, (int)expand_k, expand_tag ? 1 : 0};
         const uint64_t nt = (n_records + kPartTileK - 1) / kPartTileK;
         BBK_REQUIRE(nt < (1ull << 32), BBK_ERR_ARG, "input of %llu records exceeds the tile space", (unsigned long long)n_records);
@@ -3193,7 +3204,7 @@ struct MsdRunner {
                 if (lo >= hi) break;
                 s.lo = (uint32_t)lo;
                 s.span = (uint32_t)(hi - lo);
-                s.shl = __builtin_clz(s.span - 1u);
+                s.finish();
                 s.est = (uint64_t)((double)N * (double)(hi - lo) / 4294967296.0 * 1.04) + 1;
                 ranges.push_back(s);
             }
@@ -3212,7 +3223,7 @@ struct MsdRunner {
                 s.shl = 0;
             } else {
                 s.span = (uint32_t)span;
-                s.shl = __builtin_clz((uint32_t)span - 1u);  // span <= 2^(32 - shl)
+                s.finish();
             }
             s.est = cnt;
             if (cnt) ranges.push_back(s);
