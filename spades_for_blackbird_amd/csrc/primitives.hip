@@ -9,6 +9,7 @@
 // (kmer_index_builder.hpp:281-365).  Integer/HBM-bound work: no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -395,6 +396,10 @@ bool d2f_big(bbk_ctx *ctx, int fd, uint64_t file_off, const void *src, size_t by
         BBK_HIP(hipHostMalloc(&ctx->pinned[1], kChunk, hipHostMallocDefault));
         ctx->pinned_bytes = kChunk;
     }
+    // reserve the file's pages in one call first: concurrent writers that each allocate page-cache pages contend (tmpfs:
+    // 3-6 GB/s, noisy; pre-allocated: 6.1-6.6 GB/s whatever the writer count).  The raw syscall, not posix_fallocate: a
+    // file system without support just says so (the glibc emulation would write zeros)
+    if (!getenv("BBK_NO_FALLOCATE")) (void)fallocate(fd, 0, (off_t)file_off, (off_t)bytes);
     hipEvent_t ev[2];
     BBK_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     BBK_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
