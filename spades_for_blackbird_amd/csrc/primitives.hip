@@ -20,6 +20,7 @@
 #include <mutex>
 #include <thread>
 
+#include "arena.h"
 #include "bbk_internal.h"
 #include "kmer_ops.h"
 
@@ -57,55 +58,9 @@ constexpr size_t kPoolGranule = 2ull << 20;   // request sizes are rounded to 2 
 constexpr size_t kArenaChunk = 1ull << 30;    // physical memory is mapped in 1 GiB chunks
 constexpr size_t kArenaVA = 1ull << 40;       // reserved virtual range per arena (1 TiB)
 
-struct Arena {
+struct Arena : ArenaIndex {  // bookkeeping in arena.h (host-only, fuzzed by tests/test_arena.py)
     char *base = nullptr;
-    size_t mapped = 0;  // [base, base + mapped) is backed by physical memory
     std::vector<hipMemGenericAllocationHandle_t> chunks;
-    std::map<size_t, size_t> free_off;        // offset -> size, coalesced
-    std::multimap<size_t, size_t> free_size;  // size -> offset
-    void add_free(size_t off, size_t size) {
-        auto nx = free_off.lower_bound(off);
-        if (nx != free_off.end() && off + size == nx->first) {  // merge with the block after
-            size += nx->second;
-            erase_size(nx->second, nx->first);
-            nx = free_off.erase(nx);
-        }
-        if (nx != free_off.begin()) {
-            auto pv = std::prev(nx);
-            if (pv->first + pv->second == off) {  // merge with the block before
-                off = pv->first;
-                size += pv->second;
-                erase_size(pv->second, pv->first);
-                free_off.erase(pv);
-            }
-        }
-        free_off[off] = size;
-        free_size.emplace(size, off);
-    }
-    void erase_size(size_t size, size_t off) {
-        auto r = free_size.equal_range(size);
-        for (auto it = r.first; it != r.second; ++it)
-            if (it->second == off) {
-                free_size.erase(it);
-                return;
-            }
-    }
-    // best fit; returns false when nothing mapped is large enough
-    bool take(size_t want, size_t *off) {
-        auto it = free_size.lower_bound(want);
-        if (it == free_size.end()) return false;
-        const size_t size = it->first, o = it->second;
-        free_size.erase(it);
-        free_off.erase(o);
-        if (size > want) add_free(o + want, size - want);
-        *off = o;
-        return true;
-    }
-    size_t free_bytes() const {
-        size_t t = 0;
-        for (auto &kv : free_off) t += kv.second;
-        return t;
-    }
 };
 
 struct Pool {
@@ -132,27 +87,14 @@ int current_device() {
 }
 
 // unmaps and releases the chunks at the END of the mapped range that are completely free (all of them when nothing
-// is allocated); caller holds the lock.  hipMemUnmap waits for the device.
+// is allocated); caller holds the lock and has made sure the device is idle.
 void arena_shrink(Arena &A) {
     const double t0 = wall_s();
-    while (!A.chunks.empty()) {
-        const size_t lo = A.mapped - kArenaChunk;
-        auto it = A.free_off.upper_bound(lo);
-        if (it == A.free_off.begin()) break;
-        --it;  // the free block that starts at or before lo
-        if (it->first > lo || it->first + it->second < A.mapped) break;
-        // cut [lo, mapped) off that free block
-        const size_t off = it->first, size = it->second;
-        A.erase_size(size, off);
-        A.free_off.erase(it);
-        if (lo > off) {
-            A.free_off[off] = lo - off;
-            A.free_size.emplace(lo - off, off);
-        }
-        (void)hipMemUnmap(A.base + lo, kArenaChunk);
+    (void)hipDeviceSynchronize();
+    while (!A.chunks.empty() && A.shrink_one(kArenaChunk)) {
+        (void)hipMemUnmap(A.base + A.mapped, kArenaChunk);  // shrink_one has already lowered `mapped` by one chunk
         (void)hipMemRelease(A.chunks.back());
         A.chunks.pop_back();
-        A.mapped = lo;
         ++pool().frees;
     }
     pool().free_s += wall_s() - t0;
@@ -179,8 +121,7 @@ bool arena_grow(Arena &A, int dev, size_t n) {
             break;
         }
         A.chunks.push_back(h);
-        A.add_free(A.mapped, kArenaChunk);
-        A.mapped += kArenaChunk;
+        A.grown(kArenaChunk);
     }
     (void)hipGetLastError();
     pool().malloc_s += wall_s() - t0;
@@ -246,12 +187,7 @@ void *pool_alloc(size_t bytes, size_t *granted, int *device) {
             return A.base + off;
         }
         // grow: the request may start in the free tail of the mapped range
-        size_t tail = 0;
-        if (!A.free_off.empty()) {
-            auto last = std::prev(A.free_off.end());
-            if (last->first + last->second == A.mapped) tail = last->second;
-        }
-        const size_t need = (want - tail + kArenaChunk - 1) / kArenaChunk;
+        const size_t need = (want - A.free_tail() + kArenaChunk - 1) / kArenaChunk;
         if (!arena_grow(A, dev, need)) {
             // out of device memory: give back what other arenas of this device hold unused, and our own free tail
             // (their owners' streams may still have the last use of that memory queued: wait for the device first)
@@ -259,11 +195,7 @@ void *pool_alloc(size_t bytes, size_t *granted, int *device) {
             if (getenv("BBK_ARENA_UNMAP"))
                 for (auto &kv : pool().arenas)
                     if (kv.first.device == dev && &kv.second != &A) arena_shrink(kv.second);
-            size_t tail2 = 0;
-            if (!A.free_off.empty()) {
-                auto last = std::prev(A.free_off.end());
-                if (last->first + last->second == A.mapped) tail2 = last->second;
-            }
+            const size_t tail2 = A.free_tail();
             const size_t need2 = want > tail2 ? (want - tail2 + kArenaChunk - 1) / kArenaChunk : 0;
             if (!arena_grow(A, dev, need2)) {
                 set_error("device memory exhausted: %zu bytes requested, %.1f GB mapped, %.1f GB of it free but fragmented",
