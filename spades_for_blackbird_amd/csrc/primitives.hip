@@ -154,7 +154,22 @@ void pool_report() {
             (unsigned long long)pool().hits, (unsigned long long)pool().frees, pool().free_s, (double)mapped / 1e9);
 }
 
+static void *pool_alloc_impl(size_t bytes, size_t *granted, int *device);
+
+// BBK_POOL_POISON=1 (tests): every block handed out is filled with 0xCD first, so that code which reads device memory
+// it never wrote -- and got away with it on the driver's zero-filled fresh allocations -- fails deterministically
 void *pool_alloc(size_t bytes, size_t *granted, int *device) {
+    void *p = pool_alloc_impl(bytes, granted, device);
+    static const bool poison = getenv("BBK_POOL_POISON") != nullptr;
+    if (poison) {
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(p, 0xCD, *granted);
+        (void)hipDeviceSynchronize();
+    }
+    return p;
+}
+
+static void *pool_alloc_impl(size_t bytes, size_t *granted, int *device) {
     const size_t want = bytes <= kPoolGranule ? kPoolGranule : ((bytes + kPoolGranule - 1) / kPoolGranule) * kPoolGranule;
     const int dev = current_device();
     *device = dev;
