@@ -348,10 +348,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ctx = B.Context(local_rank, stream=torch.cuda.current_stream())
+        # BBK_BENCH_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks (the ranks share
+        # the devices, the exchange is staged through the host); the measured path is always nccl = RCCL
+        dist.init_process_group(os.environ.get("BBK_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    ctx = B.Context(dev_index, stream=torch.cuda.current_stream())
 
     k, L = args.k, args.read_len
     total_reads = args.reads * world
@@ -384,8 +387,9 @@ def main():
 
     n_rec, dt, prof = timed_steps(ctx, step, fence, args.warmup, args.steps)
 
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    nn = torch.tensor([n_rec], dtype=torch.int64, device=dev)
+    red_dev = dev if (not sharded or dist.get_backend() == "nccl") else torch.device("cpu")
+    tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    nn = torch.tensor([n_rec], dtype=torch.int64, device=red_dev)
     if sharded:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)

@@ -176,3 +176,32 @@ def test_nccl_one_rank_path():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "NCCL-ONE-RANK-OK" in r.stdout
+
+
+def test_bench_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` exactly as the driver calls it (no launcher: bench.py starts its own ranks), with
+    the collective backend switched to gloo so that both ranks can share the one GPU of the test box: the whole N>1 code
+    path of the benchmark (owner exchange, merge, expansion, max-over-ranks timing, sharded GFA build) runs end to end
+    and the aggregate equals the single-rank count of the union of the two ranks' reads."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BBK_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--reads", "200000", "--steps", "1",
+                        "--warmup", "1"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["gfa_build"]["ranks"] == 2 and line["gfa_build"]["unitigs"] > 0
+    # the union of the two ranks' reads counted by one rank
+    import spades_for_blackbird_amd as B
+    ctx = B.Context(0)
+    g = 2 * 200000 * 150 // 50
+    a = ctx.reads_synth(200000, read_len=150, genome_len=g, seed_genome=42, seed_reads=43).to_list()
+    b = ctx.reads_synth(200000, read_len=150, genome_len=g, seed_genome=42, seed_reads=44).to_list()
+    both = ctx.count(ctx.reads_from_ascii(a + b), 21, B.BOTH_STRANDS)
+    assert line["distinct_kmers"] == len(both)
+    ctx.close()
