@@ -896,6 +896,9 @@ struct BucketArgs {
     uint32_t *sorted_vals;
     uint32_t *dup_flag;
     uint64_t strip_mask;
+    // hash-dedup kernels: a probe sequence longer than this means the table is (nearly) full and the bucket is left to
+    // the caller (kHashMaxProbes; tests lower it through BBK_HASH_MAX_PROBES to force that path on half-empty slots)
+    uint32_t max_probes;
 };
 
 // first record and record count of bucket b (count 0xFFFFFFFF: the slot overflowed)
@@ -1541,7 +1544,7 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
                 const unsigned long long old = atomicCAS(&tab[slot], EMPTY, (unsigned long long)kk[i]);
                 if (old == EMPTY || old == kk[i]) break;
                 slot = (slot + 1) & (kHashSlots - 1);
-                if (kHashItems * kHashThreads > (int)(kHashSlots * 3 / 4) && ++probes > kHashMaxProbes) {
+                if (kHashItems * kHashThreads > (int)(kHashSlots * 3 / 4) && ++probes > A.max_probes) {
                     scan_tmp[14] = 1;  // give up on this bucket (benign race: everyone writes 1)
                     break;
                 }
@@ -2199,7 +2202,7 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(const uint32_t
                 const uint32_t old = atomicCAS(&tab[slot], EMPTY, kk[i]);
                 if (old == EMPTY || old == kk[i]) break;
                 slot = (slot + 1) & (kNwHashSlots - 1);
-                if (++probes > kHashMaxProbes) {
+                if (++probes > A.max_probes) {
                     scan_tmp[14] = 1;
                     break;
                 }
@@ -2383,6 +2386,10 @@ struct MsdRunner {
         }
     }
 
+    static uint32_t hash_max_probes() {
+        static const char *e = getenv("BBK_HASH_MAX_PROBES");  // tests: force the table give-up on half-empty slots
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : kHashMaxProbes;
+    }
     // unsorted dedup is enough when a later stage sorts the distinct records (HASH mode)
     bool use_hash_dedup() const { return W == 1 && dmode == MSD_HASH && 2 * k < 64; }
     bool use_hashidx_dedup() const { return W >= 2 && dmode == MSD_HASH; }
@@ -2823,7 +2830,7 @@ struct MsdRunner {
         BucketArgs A{boff.as<uint32_t>(), dcount.as<uint32_t>(), nullptr, (int)k, verbose ? dbg.as<uint32_t>() : nullptr,
                      slots ? cap2 : 0u, slots ? stride2 : 0u, hist2.as<uint32_t>(), slots ? out.keys.p : nullptr,
                      slots ? out.vals.as<uint32_t>() : nullptr, slots ? spill_n.as<uint32_t>() + 1 : nullptr,
-                     nullptr, nullptr, nullptr, ~0ull};
+                     nullptr, nullptr, nullptr, ~0ull, hash_max_probes()};
         const double bb = (double)N * (rec + (has_val ? 4 : 0));
         // Sorted output of a key array that should hold no duplicates (both strands of a distinct canonical set, odd
         // k): the dense result has the offsets of the input, so the sorting kernels write it directly -- no
@@ -3005,7 +3012,7 @@ struct MsdRunner {
                     const uint32_t hbo[2] = {0u, (uint32_t)n_extra};
                     BBK_HIP(hipMemcpyAsync(tb.p, hbo, 8, hipMemcpyHostToDevice, ctx->stream));
                     BucketArgs At{tb.as<uint32_t>(), tc.as<uint32_t>(), nullptr, (int)k, nullptr, 0u, 0u,
-                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull};
+                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull, hash_max_probes()};
                     MsdRunner<W> sorter = *this;
                     sorter.dmode = MSD_KEYS;  // picks the sorting kernels in bucket_dispatch
                     sorter.expand_k = 0;
@@ -3057,7 +3064,7 @@ struct MsdRunner {
                 DevBuf ids(big.size() * 4);
                 BBK_HIP(hipMemcpyAsync(ids.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, ctx->stream));
                 BucketArgs A2{boff.as<uint32_t>(), dcount.as<uint32_t>(), ids.as<uint32_t>(), (int)k, nullptr, 0u, 0u,
-                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull};
+                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull, hash_max_probes()};
                 const double b2 = (double)big_rec * (rec + (has_val ? 4 : 0));
                 bucket_dispatch<true>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2,
                                       /*allow_hash=*/false);

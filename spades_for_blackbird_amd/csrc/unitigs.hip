@@ -124,11 +124,27 @@ __global__ __launch_bounds__(256) void k_walk(const Key<W> *__restrict__ keys, c
     const uint32_t c0 = (uint32_t)(d & 3);
     const Key<W> canon0 = key_load<W>(&keys[i]);
     const Key<W> x = key_select<W>(s_rc, kmer_rc<W>(canon0, k), canon0);
+    // pass 1 writes the unitig's bases: 8 ASCII characters are collected in a register and leave as one 8-byte store
+    // (global memory takes unaligned 8-byte stores; one store per base was 8x the store instructions of this
+    // latency-bound walk)
+    typedef uint64_t __attribute__((aligned(1))) u64_any;
     char *dst = nullptr;
+    uint64_t pend = 0;   // characters not yet stored
+    uint32_t npend = 0;  // how many (0..7)
+    uint64_t wpos = 0;   // characters stored so far
+    auto put = [&](uint32_t base) {
+        pend |= (uint64_t)(unsigned char)"ACGT"[base] << (8 * npend);
+        if (++npend == 8) {
+            *reinterpret_cast<u64_any *>(dst + wpos) = pend;
+            wpos += 8;
+            pend = 0;
+            npend = 0;
+        }
+    };
     if (PASS == 1) {
         dst = o.bases + o.boff[e];
-        for (int j = 0; j < k; ++j) dst[j] = "ACGT"[kmer_base<W>(x, j)];
-        dst[k] = "ACGT"[c0];
+        for (int j = 0; j < k; ++j) put(kmer_base<W>(x, j));
+        put(c0);
     }
     Key<W> cur = kmer_shl<W>(x, k, c0);
     uint64_t len = 1;
@@ -152,7 +168,7 @@ __global__ __launch_bounds__(256) void k_walk(const Key<W> *__restrict__ keys, c
         const uint32_t c = (uint32_t)__builtin_ctz(m & 15u);
         prev_first = kmer_base<W>(cur, 0);
         cur = kmer_shl<W>(cur, k, c);
-        if (PASS == 1) dst[k + len] = "ACGT"[c];
+        if (PASS == 1) put(c);
         ++len;
         if (len > n + 2) {  // cannot happen on a consistent index: a start edge never re-enters itself
             atomicOr(o.err, 2u);
@@ -170,6 +186,7 @@ __global__ __launch_bounds__(256) void k_walk(const Key<W> *__restrict__ keys, c
         o.keep[e] = keep ? 1ull : 0ull;
         o.ulen[e] = keep ? (uint64_t)k + len : 0ull;
     } else {
+        for (uint32_t j = 0; j < npend; ++j) dst[wpos + j] = (char)(pend >> (8 * j));  // the last 0..7 characters
         const uint64_t u = o.uid[e];
         o.uoff[u] = o.boff[e];
         const bool selfconj = key_eq<W>(x, rcur) && c0 == 3u - prev_first;

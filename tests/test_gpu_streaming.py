@@ -116,3 +116,15 @@ def test_narrow_records_all_k():
     index, odd k), heavy repeats that overflow slots, and k = 16 / 22 on either side of the range"""
     err = _run({"BBK_MERGE_MIN": "0", "BBK_SLOTS_MIN": "0"}, 3000, 20000, (16, 17, 18, 19, 20, 21, 22))
     assert "narrow" in err
+
+
+def test_table_give_up_on_half_empty_slots_with_poisoned_memory():
+    """Slot mode, a flagged bucket whose slot is NOT full (its LDS table gave up: BBK_HASH_MAX_PROBES=0 makes every
+    collision a give-up), device memory poisoned (BBK_POOL_POISON: every allocation is filled with 0xCD, so the unwritten
+    tail of a slot holds plausible-looking garbage keys): only the records the level-2 cursor says were written may be
+    reprocessed -- the round-1 code copied the whole slot and turned stale memory into k-mers.  Counts and mask payloads
+    against the oracle, narrow (k=21) and 8-byte (k=25) hash kernels."""
+    err = _run({"BBK_MERGE_MIN": "0", "BBK_SLOTS_MIN": "0", "BBK_HASH_MAX_PROBES": "0", "BBK_POOL_POISON": "1"}, 2500, 15000,
+               (21, 25))
+    assert any("over_bkt=" in l and "over_bkt=0" not in l for l in err.splitlines() if "msd slots" in l), \
+        "no bucket was flagged: the give-up path did not run"
