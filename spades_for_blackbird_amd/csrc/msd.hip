@@ -899,6 +899,9 @@ struct BucketArgs {
     // hash-dedup kernels: a probe sequence longer than this means the table is (nearly) full and the bucket is left to
     // the caller (kHashMaxProbes; tests lower it through BBK_HASH_MAX_PROBES to force that path on half-empty slots)
     uint32_t max_probes;
+    // sorting kernels reading slots (stage B without histograms): bucket b's sorted records go to sorted_keys[out_off[b]
+    // ...] (exclusive scan of the slot fills); null: the dense layout, output offset = input offset
+    const uint32_t *out_off;
 };
 
 // first record and record count of bucket b (count 0xFFFFFFFF: the slot overflowed)
@@ -924,6 +927,7 @@ __device__ __forceinline__ void bucket_reduce(Key<W> *skeys, uint32_t *svals, ui
     constexpr int NWAVES = NT / 64;
     constexpr bool IN_VAL = OP >= 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t ostart = (A.sorted_keys && A.out_off) ? A.out_off[b] : start;  // where the sorted records go
     Key<W> mine[ITEMS];
     uint32_t mv[ITEMS];
     const uint32_t p0 = (uint32_t)tid * ITEMS;
@@ -989,7 +993,7 @@ __device__ __forceinline__ void bucket_reduce(Key<W> *skeys, uint32_t *svals, ui
                     if (A.sorted_keys) {
                         Key<W> kx = mine[i];
                         kx.w[0] &= A.strip_mask;
-                        key_store<W>(&reinterpret_cast<Key<W> *>(A.sorted_keys)[start + (uint32_t)seg], kx);
+                        key_store<W>(&reinterpret_cast<Key<W> *>(A.sorted_keys)[ostart + (uint32_t)seg], kx);
                     } else {
                         key_store<W>(&buf[start + (uint32_t)seg], mine[i]);  // distinct keys, in place
                     }
@@ -1008,7 +1012,8 @@ __device__ __forceinline__ void bucket_reduce(Key<W> *skeys, uint32_t *svals, ui
     if (OP != 0) {
         __syncthreads();
         uint32_t *vdst = A.sorted_keys ? A.sorted_vals : vals;
-        for (uint32_t s = tid; s < total; s += NT) vdst[start + s] = acc[s];
+        const uint32_t vstart = A.sorted_keys ? ostart : start;
+        for (uint32_t s = tid; s < total; s += NT) vdst[vstart + s] = acc[s];
     }
     if (tid == 0 && A.sorted_keys && total != n) atomicOr(A.dup_flag, 1u);
     if (tid == 0) A.dcount[b] = total;
@@ -1768,6 +1773,16 @@ __global__ void k_flagged(const uint32_t *__restrict__ dcount, uint32_t n, uint3
     }
 }
 
+// records every bucket slot holds (cursor - slot start, at most the slot's capacity)
+__global__ void k_slot_counts(const uint32_t *__restrict__ cursor, uint32_t n, uint32_t stride, uint32_t cap,
+                              uint64_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t c = cursor[i] - i * stride;
+        out[i] = c < cap ? c : cap;
+    }
+}
+
 __global__ void k_iota_mul(uint32_t *__restrict__ out, uint32_t n, uint32_t mul) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = i * mul;
@@ -2309,6 +2324,7 @@ struct MsdRunner {
     bool in_vals;  // records carry a payload from the start (mask extraction or input counts)
     uint64_t strip_mask = ~0ull;  // tagged sort: bits of word 0 that survive in the output
     bool slots_ok = getenv("BBK_NO_SLOTS") == nullptr;  // histogram-free slot mode allowed (HASH prefix)
+    bool kslots_ok = getenv("BBK_NO_KSLOTS") == nullptr;  // ... and for the ordering pass of a distinct key array
     bool never_decline = false;  // finish whatever overflows bucket by bucket on the LSD path instead of declining
     bool assume_distinct = false;  // caller's hint (key arrays, KEYS / REF prefix): duplicates are not expected
     unsigned expand_k = 0;         // key-array input holds CANONICAL k-mers of this length: both strands are generated
@@ -2606,10 +2622,18 @@ struct MsdRunner {
         // below on a key array.  Heavy repeats therefore cost a second pass over a small part of the data.
         const char *smin = getenv("BBK_SLOTS_MIN");  // tests lower it to run the slot mode on small inputs
         const uint64_t slots_min = smin ? strtoull(smin, nullptr, 10) : (1ull << 22);
-        const bool slots = slots_ok && !has_dst && dmode == MSD_HASH && (use_hash_dedup() || use_hashidx_dedup()) && nb1 > 1 &&
-                           N >= slots_min && (double)N / fill * 1.1 + (double)N < 4.2e9;  // u32 slot offsets
+        const bool hslots = slots_ok && !has_dst && dmode == MSD_HASH && (use_hash_dedup() || use_hashidx_dedup()) && nb1 > 1 &&
+                            N >= slots_min && (double)N / fill * 1.1 + (double)N < 4.2e9;  // u32 slot offsets
+        // Stage B (ordering a distinct key array, KEYS / REF prefix, sorted result written directly): the same slots
+        // instead of the two histogram passes.  The prefix is the key itself, so the spread is only as even as the
+        // data: ANY record that misses its slot, any bucket the sort kernel turns down, any duplicate sends the call
+        // back to the exact path (the slots cannot be patched up in key order the way the hash slots can).
+        const bool kslots = kslots_ok && slots_ok && !has_dst && !from_reads && !ranged && assume_distinct &&
+                            (dmode == MSD_KEYS || dmode == MSD_REF) && nb1 > 1 && N >= slots_min &&
+                            getenv("BBK_NO_DIRECT") == nullptr && (double)N / fill * 1.1 + (double)N < 4.2e9;
+        const bool slots = hslots || kslots;
         BBK_REQUIRE(!narrow || slots, BBK_ERR_INTERNAL, "narrow records need the slot mode");
-        const uint32_t seg_cap = slots ? ((uint32_t)((double)N / nb1 * 1.01) + 8192u) | 1u : 0u;
+        const uint32_t seg_cap = slots ? ((uint32_t)((double)N / nb1 * (kslots ? 1.06 : 1.01)) + 8192u) | 1u : 0u;
         const uint32_t cap2 = narrow ? (uint32_t)(kNwHashThreads * kNwHashItems) : bucket_cap();
         // bucket slots 256 B further apart than their capacity: with a power-of-two-ish stride every bucket's
         // fill front sits in the same HBM channel (level-2 scatter measured 10 % slower)
@@ -2727,6 +2751,10 @@ struct MsdRunner {
                 empty_out();
                 return 1;
             }
+            if (kslots && !over_seg.empty()) {
+                if (verbose) fprintf(stderr, "[bbk] msd key slots: %zu segments overflow, exact mode\n", over_seg.size());
+                return 4;
+            }
         }
         tstart[0] = 0;
         sbin[0] = 0;
@@ -2823,22 +2851,41 @@ struct MsdRunner {
         BBK_HIP(hipMemsetAsync(dbg.p, 0, 64, ctx->stream));
         // slot mode: the hash-dedup kernels write the distinct records straight into the (unordered) result
         const bool out_vals = op != MSD_OP_NONE;
-        if (slots) {
+        if (hslots) {
             out.keys.alloc((N + 16) * rec);  // upper bound; transient in every caller (expanded / exchanged next)
             if (out_vals) out.vals.alloc((N + 16) * 4);
         }
         BucketArgs A{boff.as<uint32_t>(), dcount.as<uint32_t>(), nullptr, (int)k, verbose ? dbg.as<uint32_t>() : nullptr,
-                     slots ? cap2 : 0u, slots ? stride2 : 0u, hist2.as<uint32_t>(), slots ? out.keys.p : nullptr,
-                     slots ? out.vals.as<uint32_t>() : nullptr, slots ? spill_n.as<uint32_t>() + 1 : nullptr,
-                     nullptr, nullptr, nullptr, ~0ull, hash_max_probes()};
+                     slots ? cap2 : 0u, slots ? stride2 : 0u, hist2.as<uint32_t>(), hslots ? out.keys.p : nullptr,
+                     hslots ? out.vals.as<uint32_t>() : nullptr, hslots ? spill_n.as<uint32_t>() + 1 : nullptr,
+                     nullptr, nullptr, nullptr, ~0ull, hash_max_probes(), nullptr};
         const double bb = (double)N * (rec + (has_val ? 4 : 0));
         // Sorted output of a key array that should hold no duplicates (both strands of a distinct canonical set, odd
         // k): the dense result has the offsets of the input, so the sorting kernels write it directly -- no
         // compaction pass.  Should a bucket remove a duplicate after all, or be left to the second chance, the pass
         // is redone in place (the direct pass does not touch the buckets).
-        const bool direct = !slots && assume_distinct && (dmode == MSD_KEYS || dmode == MSD_REF) &&
+        const bool direct = (!slots || kslots) && assume_distinct && (dmode == MSD_KEYS || dmode == MSD_REF) &&
                             getenv("BBK_NO_DIRECT") == nullptr;
-        DevBuf dupf;
+        DevBuf dupf, slot_off;
+        if (kslots) {
+            // dense output offsets = exclusive scan of the slot fills; a total below N means a record missed its slot
+            DevBuf c64(((size_t)nbuckets + 1) * 8);
+            hipLaunchKernelGGL(k_slot_counts, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream, hist2.as<uint32_t>(),
+                               nbuckets, stride2, cap2, c64.as<uint64_t>());
+            check_launch("k_slot_counts");
+            const uint64_t tot = exclusive_scan_u64(ctx, c64.as<uint64_t>(), c64.as<uint64_t>(), nbuckets);
+            if (tot != N) {
+                if (verbose) fprintf(stderr, "[bbk] msd key slots: %llu of %llu records placed, exact mode\n",
+                                     (unsigned long long)tot, (unsigned long long)N);
+                return 4;
+            }
+            slot_off.alloc(((size_t)nbuckets + 1) * 4 + 16);
+            hipLaunchKernelGGL(k_scan_to_u32, dim3((nbuckets + 1 + 255) / 256), dim3(256), 0, ctx->stream, c64.as<uint64_t>(),
+                               (uint64_t)nbuckets, tot, slot_off.as<uint32_t>());
+            check_launch("k_scan_to_u32");
+            BBK_HIP(hipStreamSynchronize(ctx->stream));  // c64 goes out of scope
+            A.out_off = slot_off.as<uint32_t>();
+        }
         if (direct) {
             if (!has_dst) {
                 out.keys.alloc(N * rec + 16);
@@ -2903,11 +2950,20 @@ struct MsdRunner {
         };
         fetch_flags();
         if (direct) {
-            if (ctr[2] == 0 && ctr[3] == 0) {  // every bucket sorted, nothing removed: the result is complete
-                out.n = N;
+            if (ctr[2] == 0 && ctr[3] == 0 && (!kslots || ctr[0] == 0)) {  // every bucket sorted, nothing removed or
+                out.n = N;                                                  // spilled: the result is complete
                 out.nbuckets = 0;
                 out.overflow_buckets = 0;
+                if (kslots && verbose) fprintf(stderr, "[bbk] msd key slots N=%llu buckets=%u: ordered without histograms\n",
+                                               (unsigned long long)N, nbuckets);
                 return 1;
+            }
+            if (kslots) {
+                if (verbose) fprintf(stderr, "[bbk] msd key slots given up (spill=%u flagged=%u dup=%u), exact mode\n", ctr[0],
+                                     ctr[2], ctr[3]);
+                out.keys.release();
+                out.vals.release();
+                return 4;
             }
             if (verbose) fprintf(stderr, "[bbk] msd direct output withdrawn (flagged=%u dup=%u): in-place pass\n", ctr[2], ctr[3]);
             if (!has_dst) {
@@ -3012,7 +3068,7 @@ struct MsdRunner {
                     const uint32_t hbo[2] = {0u, (uint32_t)n_extra};
                     BBK_HIP(hipMemcpyAsync(tb.p, hbo, 8, hipMemcpyHostToDevice, ctx->stream));
                     BucketArgs At{tb.as<uint32_t>(), tc.as<uint32_t>(), nullptr, (int)k, nullptr, 0u, 0u,
-                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull, hash_max_probes()};
+                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull, hash_max_probes(), nullptr};
                     MsdRunner<W> sorter = *this;
                     sorter.dmode = MSD_KEYS;  // picks the sorting kernels in bucket_dispatch
                     sorter.expand_k = 0;
@@ -3064,7 +3120,7 @@ struct MsdRunner {
                 DevBuf ids(big.size() * 4);
                 BBK_HIP(hipMemcpyAsync(ids.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, ctx->stream));
                 BucketArgs A2{boff.as<uint32_t>(), dcount.as<uint32_t>(), ids.as<uint32_t>(), (int)k, nullptr, 0u, 0u,
-                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull, hash_max_probes()};
+                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull, hash_max_probes(), nullptr};
                 const double b2 = (double)big_rec * (rec + (has_val ? 4 : 0));
                 bucket_dispatch<true>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2,
                                       /*allow_hash=*/false);
@@ -3300,6 +3356,10 @@ struct MsdRunner {
         int r = run(rd, d_keys, d_vals, n_in, with_mask, out, Sel(), &too_big);
         if (r == 3) {  // the slot mode gave up (too much of the input overflowed its slots): exact histograms
             slots_ok = false;
+            r = run(rd, d_keys, d_vals, n_in, with_mask, out, Sel(), &too_big);
+        }
+        if (r == 4) {  // the key slots of the ordering pass did not hold (skewed key space): exact histograms
+            kslots_ok = false;
             r = run(rd, d_keys, d_vals, n_in, with_mask, out, Sel(), &too_big);
         }
         if (r != 2) return r == 1;
