@@ -1899,6 +1899,12 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
     const int hb = L.narrow_hb;
     lhist[tid] = 0;  // NT == MAXB
     if (tid < MW) mark[tid] = 0ull;
+#ifdef BBK_PHASE_PROF
+    unsigned long long t_prev = clock64();
+#else
+    const unsigned long long t_prev = 0;
+    (void)t_prev;
+#endif
 
     const uint32_t tile = blockIdx.x;
     const uint64_t c0 = (uint64_t)tile * kNwChunks;
@@ -1930,12 +1936,14 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
         __syncthreads();
     }
 
+    BBK_PH(5, 0, t_prev);  // read tables + words into LDS
     uint32_t lo[ITEMS], vals[ITEMS], binrank[ITEMS];
     // (two instantiations: the address space of the packed words -- LDS or global -- must be static, a pointer that may
     // be either compiles to flat loads)
     if (fast) nw_extract<true, HAS_VAL>(S, L, k_, tid, nch, c0, r0, nr, s_rel, s_wrel, s_len, s_words, lhist, lo, vals, binrank);
     else nw_extract<false, HAS_VAL>(S, L, k_, tid, nch, c0, r0, nr, s_rel, s_wrel, s_len, s_words, lhist, lo, vals, binrank);
     __syncthreads();  // histogram complete; the read tables may be overwritten by the stage
+    BBK_PH(5, 1, t_prev);  // extraction + LDS ranking (two rounds)
 
     // scan of the 1024 bin counts (one bin per thread) and of the non-empty flags; reservation of the tile's run
     const int lane = tid & 63, wave = tid >> 6;
@@ -1967,6 +1975,7 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
         atomicOr(&mark[ex >> 6], 1ull << (ex & 63u));
     }
     __syncthreads();
+    BBK_PH(5, 2, t_prev);  // scans + reservation issue + marks
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         if (binrank[i] != 0xFFFFFFFFu) {
@@ -2004,6 +2013,7 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
         }
     }
     __syncthreads();
+    BBK_PH(5, 3, t_prev);  // reorder into LDS + mark prefix
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t pos = (uint32_t)i * NT + tid;
@@ -2025,6 +2035,10 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
             }
         }
     }
+    BBK_PH(5, 4, t_prev);  // store issue
+#ifdef BBK_PHASE_PROF
+    if (threadIdx.x == 0) atomicAdd(&g_phase[5][7], 1ull);
+#endif
 }
 
 static size_t part_reads_narrow_smem(bool has_val) {
@@ -3449,8 +3463,9 @@ struct MsdRunner {
 static void dump_phases() {
     unsigned long long h[6][8];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) != hipSuccess) return;
-    static const char *kinds[6] = {"scatter1_reads", "scatter1_keys", "scatter2", "bucket_dist", "bucket_hash", "-"};
-    for (int q = 0; q < 5; ++q) {
+    static const char *kinds[6] = {"scatter1_reads", "scatter1_keys", "scatter2", "bucket_dist", "bucket_hash",
+                                   "scatter1_narrow"};
+    for (int q = 0; q < 6; ++q) {
         if (!h[q][7]) continue;
         fprintf(stderr, "[bbk phase] %-15s wgs=%llu cycles/wg:", kinds[q], h[q][7]);
         for (int p = 0; p < 7; ++p) fprintf(stderr, " p%d=%.0f", p, (double)h[q][p] / (double)h[q][7]);
