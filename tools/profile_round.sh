@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-$PWD}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-ARGS="--k $K --no-cpu-baseline --no-gfa --no-e2e --no-k55 $*"
+ARGS="--k $K --no-cpu-baseline --no-gfa --no-e2e --no-k55 --no-meta $*"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -o stats -- python3 bench.py --steps 3 --warmup 1 $ARGS > "$OUT/bench_under_profiler.json" 2> "$OUT/stats.err"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv" 2>/dev/null
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$OUT/fetch" -o fetch -- python3 bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2> "$OUT/fetch.err"
