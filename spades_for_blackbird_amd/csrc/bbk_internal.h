@@ -160,6 +160,9 @@ struct bbk_ctx {
     // pinned staging for large device-to-host copies (pageable copies run at a fraction of PCIe)
     void *pinned[2] = {nullptr, nullptr};
     size_t pinned_bytes = 0;
+    // super-k-mer stage A (superk.hip): instances / distinct keys of the last batch it finished (0: none yet).  The
+    // buckets of the next batch are planned for that multiplicity instead of the worst case 1
+    double superk_dup = 0;
 };
 
 namespace bbk {

@@ -174,6 +174,9 @@ void dedup_reads(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_mask, 
     n_instances = 0;
     if (msd_enabled()) {
         const int op1 = with_mask ? MSD_OP_OR : (want_vals ? MSD_OP_COUNT : MSD_OP_NONE);
+        if (superk_dedup_reads(ctx, rd, k, op1, out_keys, out_vals, n_distinct, n_instances)) return;
+        n_distinct = 0;
+        n_instances = 0;
         MsdOutput a;
         if (msd_sort_reduce(ctx, k, MSD_HASH, op1, rd, nullptr, nullptr, 0, with_mask, a)) {
             n_instances = a.instances;

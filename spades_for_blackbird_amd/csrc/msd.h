@@ -34,4 +34,9 @@ bool msd_sort_reduce(bbk_ctx *ctx, unsigned k, int dmode, int op, const bbk_read
 // assume_distinct (key array, KEYS / REF prefix): the caller expects no duplicates, so the sorted result is written
 // directly at the offsets of the input (no compaction pass); verified on the fly, redone in place otherwise.
 
+// superk.hip: stage A of a batch of reads for 16- and 24-byte keys through super-k-mer records (distinct canonical
+// k-mers + count / OR of edge masks, in any order).  false: not taken or given up -- use msd_sort_reduce.
+bool superk_dedup_reads(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &out_keys, DevBuf &out_vals,
+                        uint64_t &n_distinct, uint64_t &n_instances);
+
 }  // namespace bbk

@@ -128,3 +128,36 @@ def test_table_give_up_on_half_empty_slots_with_poisoned_memory():
                (21, 25))
     assert any("over_bkt=" in l and "over_bkt=0" not in l for l in err.splitlines() if "msd slots" in l), \
         "no bucket was flagged: the give-up path did not run"
+
+
+def _superk_lines(err):
+    return [l for l in err.splitlines() if "superk" in l]
+
+
+def test_superk_records_all_wide_k():
+    """stage A through super-k-mer records (superk.hip; 16- and 24-byte keys): every pushed batch and the one-shot calls,
+    multiplicities and mask payloads (extension index) against the oracle.  k = 33 / 64 / 65 / 96 are the ends of the
+    two key widths (k = 64: no padding bits in the second word; k = 96: the window is longer than a segment), 127 stays
+    on the k-mer path.  Poisoned memory: slots and tables may only hold what the kernels wrote."""
+    err = _run({"BBK_MERGE_MIN": "0", "BBK_SUPERK_MIN": "0", "BBK_POOL_POISON": "1"}, 2500, 15000,
+               (33, 55, 63, 64, 65, 77, 96, 127))
+    lines = _superk_lines(err)
+    assert any("distinct" in l for l in lines), "the super-k-mer path did not run"
+    assert not any("declines" in l for l in lines), lines[:5]
+
+
+def test_superk_records_in_hash_range_passes():
+    """the same with 40 buckets per pass: several passes over ranges of the minimizer hash, the output regrown"""
+    err = _run({"BBK_MERGE_MIN": "0", "BBK_SUPERK_MIN": "0", "BBK_SUPERK_BUCKETS": "40"}, 2500, 15000, (55, 77))
+    lines = _superk_lines(err)
+    assert any("passes=" in l and "passes=1 " not in l for l in lines), lines[:5]
+    assert not any("declines" in l for l in lines), lines[:5]
+
+
+def test_superk_second_chance_table():
+    """buckets planned at 1.5x the first table's slots: most of them are given up and finished by the second-chance
+    geometry (8192 slots, 1024 threads)"""
+    err = _run({"BBK_MERGE_MIN": "0", "BBK_SUPERK_MIN": "0", "BBK_SUPERK_FILL": "1.5"}, 2500, 15000, (55, 77))
+    lines = _superk_lines(err)
+    assert any("second-chance table" in l for l in lines), lines[:5]
+    assert not any("declines" in l for l in lines), lines[:5]
