@@ -56,12 +56,15 @@ constexpr int kSk2Items = 8;
 constexpr int kSk2Tile = kSk2NT * kSk2Items;
 // dedup: threads (= staged records of a chunk), table slots, records that introduced a key (the table's entries point
 // into them).  First pass: four workgroups per CU (38 KB of LDS each at k = 55); buckets it gives up (table or KEEP
-// area full: several times the planned distinct keys) go to the second-chance geometry, one workgroup per CU
+// area full: several times the planned distinct keys) go to the second-chance geometry, one workgroup per CU.
+// Measured (10 M x 150 bp, k = 55, 11.8 ms): 2 ms of it without the lookups, 2 ms more with the k-mers prepared; the
+// rest is the table walk (slot -> record behind the entry -> compare).  Issuing the four lookups of a work item together
+// or walking them in lockstep was SLOWER (13.9 / 16.8 ms): the walk is bound by LDS accesses, not by their latency.
 struct SkdA {
     static constexpr int NT = 256, TS = 2048, KEEP = 384;
 };
 struct SkdB {
-    static constexpr int NT = 1024, TS = 8192, KEEP = 1024;
+    static constexpr int NT = 512, TS = 8192, KEEP = 1024;  // 512 threads: 130 KB of LDS with 24-byte keys and 13 items per record
 };
 constexpr uint32_t kSkdFailCap = 1u << 16;  // buckets the second chance takes
 constexpr uint32_t kSkdMaxProbes = 256;
@@ -450,6 +453,47 @@ __device__ __forceinline__ void sk_roll(Key<W> &F, Key<W> &RC, uint32_t k, uint3
 
 constexpr int kSkdSR = 4;  // k-mers of a work item (consecutive k-mers of one record, rolled)
 
+// F <= RC in base order (base 0 most significant, rtseq.hpp:732-741): decided by the first base in which they differ
+template <int W>
+__device__ __forceinline__ bool sk_minimal(const Key<W> &F, const Key<W> &RC) {
+    uint64_t x = 0, f = 0, r = 0;
+#pragma unroll
+    for (int i = W - 1; i >= 0; --i) {
+        const uint64_t d = F.w[i] ^ RC.w[i];
+        x = d ? d : x;
+        f = d ? F.w[i] : f;
+        r = d ? RC.w[i] : r;
+    }
+    const uint64_t t = x & (~x + 1ull);                                // lowest differing bit
+    const uint64_t lo = (t & 0x5555555555555555ull) ? t : (t >> 1);    // low bit of its base
+    const uint64_t pm = lo | (lo << 1);
+    return (f & pm) <= (r & pm);                                       // x == 0: equal, minimal
+}
+
+// table hash of a canonical k-mer: slot from the low bits, tag from the high bits
+template <int W>
+__device__ __forceinline__ uint32_t sk_khash(const Key<W> &x) {
+    uint32_t h = 0x9E3779B9u;
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        h = (h ^ (uint32_t)x.w[i]) * 0x9E3779B1u;
+        h = (h ^ (uint32_t)(x.w[i] >> 32)) * 0x85EBCA6Bu;
+        h ^= h >> 15;
+    }
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// 32 bases of a record in LDS from base p on (bits past the record's last word read as zero)
+template <int RW>
+__device__ __forceinline__ uint64_t sk_rec_bases(const uint64_t *rp, uint32_t p) {
+    const uint32_t wi = p >> 5, sh = (p & 31u) << 1;
+    const uint64_t lo = wi < (uint32_t)RW ? rp[wi] : 0ull;
+    const uint64_t hi = wi + 1u < (uint32_t)RW ? rp[wi + 1u] : 0ull;
+    return (lo >> sh) | ((hi << 1) << (63u - sh));
+}
+
 // LDS: recs[KEEP + STG][RW] u64 | ioff[STG + 2] | newidx[STG] | table[TS] | tvals[TS] (OP) | tmp[64] | work[STG * ipr] u16
 template <int W, int OP, class G>
 static size_t sk_dedup_smem(uint32_t C) {
@@ -529,24 +573,29 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
             const uint32_t cq = n - j0 < (uint32_t)SR ? n - j0 : (uint32_t)SR;
             Key<W> F = sk_kmer_at<W, RW>(rp, j0, k);
             Key<W> RC = kmer_rc<W>(F, (int)k);
+            const uint32_t inb = (uint32_t)sk_rec_bases<RW>(rp, j0 + k);  // bases j0+k, j0+k+1, ...: the ones that enter
+            uint32_t prevc = j0 > 0 ? sk_base_at(rp, j0 - 1u) : (hdr >> 14) & 3u;
             for (uint32_t u = 0; u < cq; ++u) {
                 const uint32_t j = j0 + u;
-                if (u) sk_roll<W>(F, RC, k, sk_base_at(rp, j + k - 1u));
-                const bool minimal = !kmer_less_nucl<W>(RC, F);
-                const Key<W> X = key_select<W>(minimal, F, RC), Y = key_select<W>(minimal, RC, F);
+                if (u) {
+                    prevc = (uint32_t)F.w[0] & 3u;
+                    sk_roll<W>(F, RC, k, (inb >> (2u * (u - 1u))) & 3u);
+                }
+                const bool minimal = sk_minimal<W>(F, RC);
+                const Key<W> X = key_select<W>(minimal, F, RC);
                 uint32_t val = 1;
                 if (OP == 3) {
                     const bool hp = j > 0 || ((hdr >> 13) & 1u), hn = j + 1u < n || ((hdr >> 16) & 1u);
-                    const uint32_t prevc = j > 0 ? sk_base_at(rp, j - 1u) : (hdr >> 14) & 3u;
-                    const uint32_t nextc = j + 1u < n ? sk_base_at(rp, j + k) : (hdr >> 17) & 3u;
+                    const uint32_t nextc = j + 1u < n ? (inb >> (2u * u)) & 3u : (hdr >> 17) & 3u;
                     val = 0;
                     if (hn) val |= 1u << (minimal ? nextc : 7u - nextc);
                     if (hp) val |= 1u << (minimal ? 4u + prevc : 3u - prevc);
                 }
-                const uint32_t h = part_hash32<W>(X);
+                const uint32_t h = sk_khash<W>(X);
                 const uint32_t tag = (h >> 19) & 0x1FFFu;
+                const uint32_t strand = minimal ? 0u : 1u;
                 // entry: tag 13 | record index 11 (KEEP area, then staging) | offset 6 | strand 1; bit 31 clear
-                const uint32_t entry = (tag << 18) | (((uint32_t)KEEP + r) << 7) | (j << 1) | (minimal ? 0u : 1u);
+                const uint32_t entry = (tag << 18) | (((uint32_t)KEEP + r) << 7) | (j << 1) | strand;
                 uint32_t slot = h & (uint32_t)(TS - 1);
                 bool done = false;
                 for (uint32_t p = 0; p < kSkdMaxProbes; ++p) {
@@ -560,8 +609,10 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
                         }
                     }
                     if ((e >> 18) == tag) {
+                        // same canonical k-mer <=> the entry's forward bits equal my forward bits (same strand) or my
+                        // reverse complement (opposite strands)
                         const Key<W> G = sk_kmer_at<W, RW>(recs + ((e >> 7) & 2047u) * RW, (e >> 1) & 63u, k);
-                        if (key_eq<W>(G, (e & 1u) ? Y : X)) {
+                        if (key_eq<W>(G, key_select<W>((e & 1u) == strand, F, RC))) {
                             done = true;
                             break;
                         }
@@ -750,7 +801,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     // a quarter full would spend most of the kernel's time on them.  A batch that turns out less repetitive sends
     // its fuller buckets to the second-chance table (4x the slots) and, past 65536 of those, back to the k-mer path.
     const char *ef = getenv("BBK_SUPERK_FILL");  // tests: overfull buckets exercise the second-chance table
-    const double dup_plan = std::min(8.0, std::max(1.0, 0.8 * ctx->superk_dup));
+    const double dup_plan = std::min(4.0, std::max(1.0, 0.8 * ctx->superk_dup));
     const double fill = ef ? atof(ef) : 0.55 * dup_plan;
     const double nb_total = std::max(1.0, std::ceil((double)N / (fill * SkdA::TS)));
     const char *eb = getenv("BBK_SUPERK_BUCKETS");
@@ -779,7 +830,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     const uint64_t nbuckets = (uint64_t)P1 * P2;
     if ((uint64_t)P1 * P.tps >= (1ull << 31)) return false;
     const size_t sm1 = sk_part1_smem(C, P1, RW);
-    if (sm1 > 160 * 1024) return false;
+    if (sm1 > 160 * 1024 || sk_dedup_smem<W, 3, SkdA>(C) > 160 * 1024 || sk_dedup_smem<W, 3, SkdB>(C) > 160 * 1024) return false;
     if (verbose)
         fprintf(stderr,
                 "[bbk] superk: k=%u m=%u w=%u C=%u segs=%llu est_records=%.0f passes=%u P1=%u P2=%u slot1=%u lds1=%zu fill=%.2f\n",
@@ -801,7 +852,8 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     // output: distinct records are appended; sized from the multiplicity the caller is likely to see and regrown if
     // a pass runs over (its dedup kernel is then run again: the buckets are still there)
     const size_t key_bytes = (size_t)W * 8;
-    uint64_t out_cap = std::min<uint64_t>(N, N / 3 + (1u << 20));
+    uint64_t out_cap = std::min<uint64_t>(
+        N, (uint64_t)(ctx->superk_dup >= 1.0 ? (double)N / ctx->superk_dup * 1.15 : (double)N / 3.0) + (1u << 20));
     DevBuf okeys(out_cap * key_bytes + 16), ovals;
     if (op != MSD_OP_NONE) ovals.alloc(out_cap * 4 + 16);
 
@@ -909,7 +961,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     n_instances = N;
     n_distinct = D;
     ctx->add_stat("stat_superk_batches", 1);
-    ctx->superk_dup = D ? (double)N / (double)D : 0.0;
+    if (N >= (1ull << 20)) ctx->superk_dup = D ? (double)N / (double)D : 0.0;  // a small batch says little about the next
     if (verbose) fprintf(stderr, "[bbk] superk: %llu instances -> %llu distinct\n", (unsigned long long)N, (unsigned long long)D);
     // the caller keeps the result for the rest of the job: do not leave it in a buffer sized for the estimate
     if (out_cap > D + D / 8 + (1u << 20)) {
