@@ -17,6 +17,11 @@ import re
 import sys
 
 FAMILY = [  # k_part_reads<W, HAS_VAL, HIST_ONLY>, k_part<W, HAS_VAL, HIST_ONLY, LVL1>
+    (r"k_sk_part1", "sk_part1"),
+    (r"k_sk_part2<\d, true>", "sk_hist2"),
+    (r"k_sk_part2<\d, false>", "sk_part2"),
+    (r"k_sk_dedup<.*SkdB>", "sk_dedup2"),
+    (r"k_sk_dedup", "sk_dedup"),
     (r"k_part_reads_narrow", "part_scatter1_reads"),
     (r"k_part_narrow2", "part_scatter2"),
     (r"k_bucket_hash32", "lds_dedup"),
