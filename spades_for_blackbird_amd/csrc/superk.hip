@@ -68,7 +68,9 @@ struct SkdB {
 };
 constexpr uint32_t kSkdFailCap = 1u << 16;  // buckets the second chance takes
 constexpr uint32_t kSkdMaxProbes = 256;
-constexpr uint32_t kSkMaxP1Bits = 10, kSkMaxP2 = 1024;
+// level 2 takes up to 4096 bins per slot: with more than ~1000 a tile of 2048 records leaves single records per bin
+// (each its own 24-byte store), which costs far less than another pass over the reads (38 ms per 100 M reads)
+constexpr uint32_t kSkMaxP1Bits = 10, kSkMaxP2 = 4096;
 
 struct SkParams {
     uint32_t k, m, w, C;      // k-mer, minimizer, window (m-mers of a k-mer), k-mers of a segment
@@ -768,6 +770,9 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     constexpr int RW = W + 1;
     const bool verbose = getenv("BBK_VERBOSE") != nullptr;
     if (rd->n == 0 || rd->n >= (1ull << 32)) return false;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+    double t_setup = 0, t_alloc = 0, t_passes = 0;
     // geometry: the record holds nbase_max bases -> runs of up to n_cap k-mers; the minimizer is as long as it can be
     // without natural runs (<= k-m+1 k-mers) exceeding the record, within [15, 31]
     const uint32_t nbase_max = (64u * RW - kSkHdrBits) / 2u;
@@ -841,6 +846,10 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
                        rd->n, ntiles1, (uint32_t)kSk1NT, n_segs, tiles.as<SkTile>());
     check_launch("k_sk_tiles");
     SkReads S{rd->d_words, rd->d_woff, rd->d_len, coff.as<uint64_t>(), tiles.as<SkTile>(), rd->n, n_segs};
+    if (verbose) {
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        t_setup = since();
+    }
 
     const size_t rec_bytes = (size_t)RW * 8;
     DevBuf buf1((size_t)P1 * P.slot1 * rec_bytes), buf2;
@@ -860,6 +869,10 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     {
         auto fn1 = k_sk_part1<RW>;
         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1));
+    }
+    if (verbose) {
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        t_alloc = since();
     }
     uint32_t hflags[16];
     unsigned long long done_before = 0;
@@ -957,12 +970,18 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     }
     buf1.release();
     buf2.release();
+    if (verbose) t_passes = since();
     const uint64_t D = done_before;
     n_instances = N;
     n_distinct = D;
     ctx->add_stat("stat_superk_batches", 1);
     if (N >= (1ull << 20)) ctx->superk_dup = D ? (double)N / (double)D : 0.0;  // a small batch says little about the next
-    if (verbose) fprintf(stderr, "[bbk] superk: %llu instances -> %llu distinct\n", (unsigned long long)N, (unsigned long long)D);
+    auto report = [&]() {
+        if (verbose)
+            fprintf(stderr, "[bbk] superk: %llu instances -> %llu distinct; wall %.3f s (setup %.3f, buffers %.3f, passes %.3f, result %.3f)\n",
+                    (unsigned long long)N, (unsigned long long)D, since(), t_setup, t_alloc - t_setup, t_passes - t_alloc,
+                    since() - t_passes);
+    };
     // the caller keeps the result for the rest of the job: do not leave it in a buffer sized for the estimate
     if (out_cap > D + D / 8 + (1u << 20)) {
         DevBuf xk(D * key_bytes + 16), xv;
@@ -978,6 +997,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
         out_keys = std::move(okeys);
         if (op != MSD_OP_NONE) out_vals = std::move(ovals);
     }
+    report();
     return true;
 }
 
