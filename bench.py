@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md), the figure fractions are quoted against
 FAMILIES = ["extract", "hist", "scan", "scatter", "unique", "reduce", "expand", "part_hist0", "part_hist1_reads",
             "part_hist1_keys", "part_scatter1_reads", "part_scatter1_keys", "part_hist2", "part_scatter2", "lds_dedup",
-            "lds_sort", "compact", "sk_part1", "sk_hist2", "sk_part2", "sk_dedup", "sk_dedup2"]
+            "lds_sort", "compact", "sk_part1", "sk_hist2", "sk_part2", "sk_dedup", "sk_dedup2", "part_scatter0_keys"]
 # HBM traffic from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate runs of this very
 # command and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py).  A profiler cannot run
 # inside the timed process, so the committed summary is attached when the workload is the one it was

@@ -3322,7 +3322,34 @@ struct MsdRunner {
         };
         bool ok = true;
         if (dmode == MSD_KEYS) {
-            ok = greedy(0, 1u << FB);
+            // equal aligned pieces of the key space when they fit a pass (b0 bits: 2, 4, ... 64 pieces): run_all can then
+            // split the input into them with ONE partition pass instead of selecting a piece from the whole input per pass
+            int b0 = 0;
+            for (int b = 1; b <= 6 && !b0; ++b) {
+                const uint32_t per = (1u << FB) >> b;
+                bool fits = true;
+                for (uint32_t f = 0; f < (1u << FB) && fits; f += per) {
+                    uint64_t t = 0;
+                    for (uint32_t j = 0; j < per; ++j) t += h[f + j];
+                    fits = t <= limit;
+                }
+                if (fits) b0 = b;
+            }
+            if (b0) {
+                const uint32_t per = (1u << FB) >> b0;
+                for (uint32_t f = 0; f < (1u << FB); f += per) {
+                    uint64_t t = 0;
+                    for (uint32_t j = 0; j < per; ++j) t += h[f + j];
+                    Sel sp;  // kept even when empty: the pieces stay equal and aligned
+                    sp.lo = f << (32 - FB);
+                    sp.span = per << (32 - FB);
+                    sp.finish();
+                    sp.est = t;
+                    ranges.push_back(sp);
+                }
+            } else {
+                ok = greedy(0, 1u << FB);
+            }
         } else {  // MSD_REF: fine ranges 32 x b .. 32 x b + 31 make up XXH3 bucket b
             constexpr uint32_t per = (1u << FB) / 16;
             uint64_t bt[16];
@@ -3359,6 +3386,108 @@ struct MsdRunner {
         return ok;
     }
 
+    // Key-array input in R >= 3 equal, aligned ranges of the prefix space (KEYS: pieces of the key space; REF: groups of
+    // XXH3 buckets): selecting one range from the WHOLE input per pass reads -- and for an expanded canonical array
+    // regenerates -- everything R times, twice (histogram + scatter), and keeps 1/R of every tile.  Instead a "level 0"
+    // partition pass writes the records grouped by range once (the counts are already known from the planning
+    // histogram), and every range is then an ordinary key array.  Level 0 runs in chunks of 2^j ranges that stay below
+    // the 32-bit record offsets of one pass.  false: not applicable (the caller selects per pass as before).
+    bool level0_ranges(const void *d_keys, const uint32_t *d_vals, uint64_t n_in, uint64_t Nrec, const std::vector<Sel> &ranges,
+                       MsdOutput &out, uint64_t &D, uint64_t &inst) {
+        constexpr uint32_t kPartTileK = PartCfg<W>::TILE;
+        const size_t R = ranges.size();
+        if (R < 3 || (R & (R - 1)) || getenv("BBK_NO_LEVEL0")) return false;
+        const uint32_t span = ranges[0].span;
+        if (span == 0 || (span & (span - 1))) return false;
+        for (size_t i = 0; i < R; ++i)
+            if (ranges[i].span != span || ranges[i].lo != (uint32_t)(i * (uint64_t)span)) return false;
+        if ((uint64_t)span * R != (1ull << 32)) return false;
+        const bool verbose = getenv("BBK_VERBOSE") != nullptr;
+        const bool has_val = d_vals != nullptr;
+        const size_t rec = (size_t)W * 8;
+        const int w0bits = (W == 1) ? (int)(2 * k) : 64;
+        // ranges per chunk: the largest power of two whose chunks all stay below the pass's 32-bit offsets
+        size_t m = R;
+        for (; m > 1; m >>= 1) {
+            bool fits = true;
+            for (size_t c = 0; c < R && fits; c += m) {
+                uint64_t t = 0;
+                for (size_t j = 0; j < m; ++j) t += ranges[c + j].est;
+                fits = t < (3500ull << 20);
+            }
+            if (fits) break;
+        }
+        if (m < 2) return false;
+        int jbits = 0;
+        while ((1u << jbits) < m) ++jbits;
+        const uint64_t Ntot = expand_k ? 2 * n_in : n_in;  // instance space of the level-0 tiles
+        const uint64_t nt = (Ntot + kPartTileK - 1) / kPartTileK;
+        if (nt >= (1ull << 32)) return false;
+        const unsigned ek = expand_k;
+        const bool et = expand_tag;
+        auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        for (size_t c = 0; c < R; c += m) {
+            std::vector<uint32_t> off(m + 1, 0);
+            for (size_t j = 0; j < m; ++j) off[j + 1] = off[j] + (uint32_t)ranges[c + j].est;
+            const uint64_t nc = off[m];
+            if (nc == 0) continue;
+            const double t0 = wall();
+            DevBuf buf0(nc * rec + 16), val0, cur(m * 4 + 16);
+            if (has_val) val0.alloc(nc * 4 + 16);
+            BBK_HIP(hipMemcpyAsync(cur.p, off.data(), m * 4, hipMemcpyHostToDevice, ctx->stream));
+            Sel cs;
+            cs.lo = ranges[c].lo;
+            const uint64_t cspan = (uint64_t)span * m;
+            if (cspan < (1ull << 32)) {
+                cs.span = (uint32_t)cspan;
+                cs.finish();
+            }
+            PartLevel L0{1, jbits, (uint32_t)m, dmode, w0bits, nullptr, nullptr, cs.lo, cs.span, cs.shl, cs.mul};
+            TileMap M0{nullptr, nullptr, nullptr, 1, Ntot, 0, 1, nullptr, (int)ek, et ? 1 : 0};
+            const double pb = (double)(ek ? n_in : Ntot) * (rec + (has_val ? 4 : 0)) + (double)nc * (rec + (has_val ? 4 : 0));
+            if (has_val)
+                launch_part<true, false>("part_scatter0_keys", pb, (uint32_t)nt, (const Key<W> *)d_keys, d_vals, M0, L0, nullptr,
+                                         cur.as<uint32_t>(), buf0.as<Key<W>>(), val0.as<uint32_t>());
+            else
+                launch_part<false, false>("part_scatter0_keys", pb, (uint32_t)nt, (const Key<W> *)d_keys, nullptr, M0, L0, nullptr,
+                                          cur.as<uint32_t>(), buf0.as<Key<W>>(), nullptr);
+            std::vector<uint32_t> end(m);
+            BBK_HIP(hipMemcpyAsync(end.data(), cur.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));
+            for (size_t j = 0; j < m; ++j)
+                BBK_REQUIRE(end[j] == off[j + 1], BBK_ERR_INTERNAL, "level 0: range %zu received %u records, planned %u", c + j,
+                            end[j] - off[j], off[j + 1] - off[j]);
+            if (verbose) fprintf(stderr, "[bbk] level 0: %llu records into %zu ranges: %.3f s\n", (unsigned long long)nc, m, wall() - t0);
+            // every range of the chunk: an ordinary key array (its records are what the expansion generated)
+            expand_k = 0;
+            expand_tag = false;
+            struct Restore {
+                MsdRunner *r;
+                unsigned ek;
+                bool et;
+                ~Restore() {
+                    r->expand_k = ek;
+                    r->expand_tag = et;
+                }
+            } restore{this, ek, et};
+            for (size_t j = 0; j < m; ++j) {
+                const Sel &sr = ranges[c + j];
+                if (sr.est == 0) continue;
+                MsdOutput part;
+                Dst dst{out.keys.as<char>() + D * rec, out.vals.p ? out.vals.as<uint32_t>() + D : nullptr};
+                const double t1 = wall();
+                const int rv = run(nullptr, buf0.as<char>() + (size_t)off[j] * rec, has_val ? val0.as<uint32_t>() + off[j] : nullptr,
+                                   sr.est, false, part, sr, nullptr, dst);
+                if (verbose) fprintf(stderr, "[bbk] key range (materialised): %.3f s\n", wall() - t1);
+                BBK_REQUIRE(rv == 1, BBK_ERR_INTERNAL, "a materialised range did not sort (%d)", rv);
+                D += part.n;
+                inst += part.instances;
+            }
+        }
+        (void)Nrec;
+        return true;
+    }
+
     // run() plus the split into ranges of the prefix space when the input holds more records than one pass takes
     // (what the reference does with bounded buffers, repeated DumpBuffers rounds and the run merge,
     // kmer_splitter.hpp:73-167, kmer_index_builder.hpp:281-365).  HASH prefix: every hash range is deduplicated on
@@ -3388,7 +3517,18 @@ struct MsdRunner {
             // stage B sorts a distinct set)
             out.keys.alloc(Nrec * rec + 16);
             if (out_vals) out.vals.alloc(Nrec * 4 + 16);
+            if (level0_ranges(d_keys, d_vals, n_in, Nrec, ranges, out, D, inst)) {
+                BBK_REQUIRE(inst == Nrec, BBK_ERR_INTERNAL, "range passes saw %llu of %llu records", (unsigned long long)inst,
+                            (unsigned long long)Nrec);
+                out.n = D;
+                out.instances = Nrec;
+                out.nbuckets = 0;
+                return true;
+            }
+            D = 0;
+            inst = 0;
             for (const Sel &sr : ranges) {
+                if (sr.est == 0) continue;
                 MsdOutput part;
                 Dst dst{out.keys.as<char>() + D * rec, out_vals ? out.vals.as<uint32_t>() + D : nullptr};
                 const double t0k = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
