@@ -161,3 +161,51 @@ def test_superk_second_chance_table():
     lines = _superk_lines(err)
     assert any("second-chance table" in l for l in lines), lines[:5]
     assert not any("declines" in l for l in lines), lines[:5]
+
+
+@pytest.mark.parametrize("k", [55, 77])
+def test_superk_equals_kmer_path_at_size(k, monkeypatch):
+    """3 M x 150 bp (0.29 G instances: the super-k-mer path's default threshold is 4 M, its buckets, slots and tables are
+    the planned sizes, several thousand buckets go through the second chance with a second batch planned for the first
+    one's multiplicity): the canonical set with multiplicities and the extension index (keys + edge masks) must be
+    identical, element by element, to what the k-mer path (BBK_NO_SUPERK=1) gives -- compared on the device."""
+    import torch
+    import spades_for_blackbird_amd as B
+    ctx = B.Context(0, stream=torch.cuda.current_stream())
+    n_reads, L = 3_000_000, 150
+    r = ctx.reads_synth(n_reads, read_len=L, genome_len=n_reads * L // 20, seed_genome=7, seed_reads=8)
+    W = (k + 31) // 32
+
+    def run():
+        out = []
+        for _ in range(2):  # the second call is planned from the multiplicity the first one saw
+            s = ctx.count(r, k, B.CANONICAL | B.WITH_COUNTS)
+            n = len(s)
+            assert s.instances == n_reads * (L - k + 1)
+            keys = torch.empty((n, W), dtype=torch.int64, device="cuda")
+            cnt = torch.empty(n, dtype=torch.int32, device="cuda")
+            s.export_to(keys, B.ORDER_SORTED, cnt)
+            s.free()
+            out.append((keys, cnt))
+        x = ctx.extindex(r, k)
+        xk = torch.empty((len(x), W), dtype=torch.int64, device="cuda")
+        xm = torch.empty(len(x), dtype=torch.int32, device="cuda")
+        x.export_to_u32(xk, xm)
+        return out, xk, xm
+
+    ctx.profile(True)
+    ctx.profile_reset()
+    a, ak, am = run()
+    assert ctx.profile_get("sk_dedup")["launches"] >= 3, "the super-k-mer path did not run"
+    assert ctx.profile_get("stat_superk_declined")["launches"] == 0
+    monkeypatch.setenv("BBK_NO_SUPERK", "1")
+    ctx.profile_reset()
+    b, bk, bm = run()
+    assert ctx.profile_get("sk_dedup")["launches"] == 0
+    for (k1, c1), (k2, c2) in zip(a, b):
+        assert k1.shape == k2.shape and bool(torch.equal(k1, k2)) and bool(torch.equal(c1, c2))
+        assert int(c1.sum(dtype=torch.int64).item()) == n_reads * (L - k + 1)
+    assert bool(torch.equal(a[0][0], a[1][0])) and bool(torch.equal(a[0][1], a[1][1]))
+    assert ak.shape == bk.shape and bool(torch.equal(ak, bk)) and bool(torch.equal(am, bm))
+    assert bool(torch.equal(ak, a[0][0]))  # the extension index holds exactly the canonical k-mers
+    ctx.close()
