@@ -1,4 +1,4 @@
-// superk.hip -- stage A for wide k-mers (33 <= k <= 96, 16- and 24-byte keys): the duplicate-heavy canonical stream
+// superk.hip -- stage A for wide k-mers (33 <= k <= 127: 16-, 24- and 32-byte keys): the duplicate-heavy canonical stream
 // travels between the partition levels as SUPER-K-MER records instead of one key per k-mer.
 //
 // Why: at k = 55 a 150 bp read holds 96 k-mers = 1536 bytes of 16-byte keys, which the k-mer path (msd.hip) writes
@@ -7,7 +7,7 @@
 // run that share their MINIMIZER (the m-mer of the k-mer whose canonical form hashes lowest) go to the same bucket
 // when buckets are chosen by the minimizer, and so do all other occurrences of those k-mers, on either strand: the
 // canonical m-mers of a k-mer and of its reverse complement are the same set.  A record of RW = W+1 words holds up to
-// 86 (118) bases = a run of up to 32 k-mers at k = 55: ~9 records = 210 bytes per read instead of 1536.
+// 86 (118, 150) bases = a run of up to 32 k-mers at k = 55: ~9 records = 210 bytes per read instead of 1536.
 //
 //   k_sk_part1 : one lane per segment of C consecutive k-mers of one read.  Sliding-window minimum without divergence:
 //                the window of w = k-m+1 m-mer positions of k-mer i is a suffix of block A = [s, s+w) and a prefix of
@@ -1011,6 +1011,7 @@ bool superk_dedup_reads(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, D
     const unsigned W = words_of(k);
     if (W == 2) return superk_run<2>(ctx, rd, k, op, out_keys, out_vals, n_distinct, n_instances);
     if (W == 3) return superk_run<3>(ctx, rd, k, op, out_keys, out_vals, n_distinct, n_instances);
+    if (W == 4) return superk_run<4>(ctx, rd, k, op, out_keys, out_vals, n_distinct, n_instances);
     return false;
 }
 

@@ -135,12 +135,12 @@ def _superk_lines(err):
 
 
 def test_superk_records_all_wide_k():
-    """stage A through super-k-mer records (superk.hip; 16- and 24-byte keys): every pushed batch and the one-shot calls,
-    multiplicities and mask payloads (extension index) against the oracle.  k = 33 / 64 / 65 / 96 are the ends of the
-    two key widths (k = 64: no padding bits in the second word; k = 96: the window is longer than a segment), 127 stays
-    on the k-mer path.  Poisoned memory: slots and tables may only hold what the kernels wrote."""
+    """stage A through super-k-mer records (superk.hip; 16-, 24- and 32-byte keys): every pushed batch and the one-shot calls,
+    multiplicities and mask payloads (extension index) against the oracle.  k = 33 / 64 / 65 / 96 / 97 / 127 are the ends
+    of the three key widths (k = 64: no padding bits in the second word; k = 96: the window is longer than a segment;
+    k = 127: records of 24 k-mers in five words).  Poisoned memory: slots and tables may only hold what the kernels wrote."""
     err = _run({"BBK_MERGE_MIN": "0", "BBK_SUPERK_MIN": "0", "BBK_POOL_POISON": "1"}, 2500, 15000,
-               (33, 55, 63, 64, 65, 77, 96, 127))
+               (33, 55, 63, 64, 65, 77, 96, 97, 127))
     lines = _superk_lines(err)
     assert any("distinct" in l for l in lines), "the super-k-mer path did not run"
     assert not any("declines" in l for l in lines), lines[:5]
