@@ -402,7 +402,9 @@ static void expand_both_strands(bbk_ctx *ctx, unsigned k, const DevBuf &ck, cons
         // fused: the level-1 partition kernels generate key, reverse complement (and tag) from the canonical array
         // themselves -- the expanded array is never written
         MsdOutput m;
-        const bool ref_prefix = want_ref && !tag && W <= 2;
+        // REF prefix (XXH3 bucket above the key bits: the final_kmers order straight from the sort) for every key
+        // width; BBK_NO_WIDE_REF=1: keys above 16 bytes are sorted ascending and take one more stable pass on the bucket
+        const bool ref_prefix = want_ref && !tag && (W <= 2 || getenv("BBK_NO_WIDE_REF") == nullptr);
         if (msd_sort_reduce(ctx, k, ref_prefix ? MSD_REF : MSD_KEYS, wc ? MSD_OP_SUM : MSD_OP_NONE, nullptr, ck.p,
                             wc ? cv->as<uint32_t>() : nullptr, D, false, m, tag ? 4u : 0u,
                             /*assume_distinct: odd k has no self-reverse-complementary k-mers*/ (k & 1) != 0,
