@@ -209,3 +209,11 @@ def test_superk_equals_kmer_path_at_size(k, monkeypatch):
     assert ak.shape == bk.shape and bool(torch.equal(ak, bk)) and bool(torch.equal(am, bm))
     assert bool(torch.equal(ak, a[0][0]))  # the extension index holds exactly the canonical k-mers
     ctx.close()
+
+
+def test_superk_gives_up_and_the_kmer_path_takes_over():
+    """buckets planned 64x over the table: the first chance lists them, the second chance fails too, the call is
+    given up and the batch is run on the k-mer path -- same results, and the next batch starts from scratch"""
+    err = _run({"BBK_MERGE_MIN": "0", "BBK_SUPERK_MIN": "0", "BBK_SUPERK_FILL": "64"}, 2500, 15000, (55,))
+    lines = _superk_lines(err)
+    assert any("declines" in l for l in lines), lines[:5]
