@@ -24,13 +24,18 @@
 //                keys + reduced payload (count or OR of edge masks) are appended to the output through one global
 //                atomic per bucket.
 //
-// The level-1 slots and the dedup table are sized from estimates; one that runs over raises a flag and the caller (count.hip: dedup_reads) reruns the batch on the k-mer path -- low-complexity input (one minimizer
-// shared by millions of distinct k-mers) ends up there.  Inputs above 1 M buckets run in passes over ranges of the
-// minimizer hash; every pass re-reads the packed reads (0.4 GB per 10 M reads), never the k-mers.
+// The level-1 slots and the dedup tables are sized from estimates; what does not fit is not lost: records beyond a full
+// level-1 slot go to a spill list and their buckets, like the buckets whose distinct keys exceed both table geometries
+// (a low-complexity minimizer shared by thousands of k-mers), are expanded into one key per instance and deduplicated by
+// the k-mer path (k_sk_expand + msd_sort_reduce), bucket by bucket.  Only when that share is large does the call return
+// false and the caller (count.hip: dedup_reads) rerun the whole batch on the k-mer path.  Inputs above 3.8 M buckets run
+// in passes over ranges of the minimizer hash; every pass re-reads the packed reads (0.4 GB per 10 M reads), never the
+// k-mers.
 // The output order is arbitrary (HASH semantics): stage B / the accumulator sort it.
 // Environment: BBK_NO_SUPERK (A/B switch), BBK_SUPERK_MIN (instances below which the k-mer path is used; tests set 0),
 // BBK_SUPERK_BUCKETS (tests: buckets per pass, forces several passes on small inputs), BBK_SUPERK_FILL (tests: planned
-// instances of a bucket / table slots), BBK_VERBOSE.
+// instances of a bucket / table slots), BBK_SUPERK_SLOT_SCALE (tests: level-1 slots below their load),
+// BBK_SUPERK_FALLBACK_MAX (share of a batch's instances the k-mer path may take over, default 0.25), BBK_VERBOSE.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -78,6 +83,7 @@ struct SkParams {
     uint32_t b1bits, P1, P2;  // level-1 bins (power of two), level-2 bins of every level-1 slot
     uint32_t slot1;           // records of a level-1 slot
     uint32_t tps;             // level-2 tiles of a level-1 slot
+    uint32_t spill_cap;       // records the level-1 spill list holds
 };
 
 struct SkTile {
@@ -94,7 +100,17 @@ struct SkReads {
     uint64_t n_segs;
 };
 
-enum { SKF_SLOT1 = 0, SKF_NFAIL = 1, SKF_TABLE = 2, SKF_STAGE = 3, SKF_OUT = 4, SKF_SELECT = 5, SKF_MAXREC = 6 };
+enum {
+    SKF_SLOT1 = 0,   // too many bins of one tile ran over their level-1 slot, or the spill list is full: give up
+    SKF_NFAIL = 1,   // buckets the first table gave up (listed)
+    SKF_TABLE = 2,   // more buckets for the k-mer path than its list holds: give up
+    SKF_STAGE = 3,
+    SKF_OUT = 4,     // output buffer too small (regrown, pass repeated)
+    SKF_SELECT = 5,
+    SKF_MAXREC = 6,
+    SKF_NSPILL = 7,  // records that did not fit their level-1 slot (spill list)
+    SKF_NFAIL2 = 8   // buckets left to the k-mer path (hot: a spilled record belongs to them; or both tables gave up)
+};
 
 // hash of a canonical m-mer (F forward, R reverse complement, both right-aligned 2m bits)
 __device__ __forceinline__ uint32_t sk_mhash(uint64_t F, uint64_t R) {
@@ -222,8 +238,14 @@ static size_t sk_part1_smem(uint32_t C, uint32_t P1, int RW) {
 // minimizer positions in the genome several positions share a value and the bucket sizes spread out.
 template <int RW>
 __global__ __launch_bounds__(kSk1NT) void k_sk_part1(SkReads S, SkParams P, uint32_t *__restrict__ cursor1,
-                                                     uint64_t *__restrict__ out, uint32_t *__restrict__ flags) {
+                                                     uint64_t *__restrict__ out, uint64_t *__restrict__ spill,
+                                                     uint32_t *__restrict__ flags) {
     constexpr int NT = kSk1NT;
+    // bins of this tile whose run does not fit the rest of their slot (a hot minimizer): {base, records that fit,
+    // position in the spill list}; their gbase entry is 0x80000000 | index
+    __shared__ uint32_t ovf[64][3];
+    __shared__ uint32_t ovf_n;
+    if (threadIdx.x == 0) ovf_n = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // layout: sufA[C][NT] u32 (suffix minima, then one word per record: bin | rank) | lhist[P1] | gbase[P1] |
     //         posA[C][NT] u8 (position of the minimum relative to the segment, then relative to the record)
@@ -323,8 +345,21 @@ __global__ __launch_bounds__(kSk1NT) void k_sk_part1(SkReads S, SkParams P, uint
         uint32_t g = 0xFFFFFFFFu;
         if (cb) {
             const uint32_t base = atomicAdd(&cursor1[b], cb);
-            if (base + cb <= P.slot1) g = base;
-            else flags[SKF_SLOT1] = 1u;
+            if (base + cb <= P.slot1) {
+                g = base;
+            } else {  // what fits goes to the slot, the rest to the spill list
+                const uint32_t fit = base >= P.slot1 ? 0u : P.slot1 - base;
+                const uint32_t sb = atomicAdd(&flags[SKF_NSPILL], cb - fit);
+                const uint32_t idx = atomicAdd(&ovf_n, 1u);
+                if (idx < 64u && sb + (cb - fit) <= P.spill_cap) {
+                    ovf[idx][0] = base;
+                    ovf[idx][1] = fit;
+                    ovf[idx][2] = sb;
+                    g = 0x80000000u | idx;
+                } else {
+                    flags[SKF_SLOT1] = 1u;
+                }
+            }
         }
         gbase[b] = g;
     }
@@ -353,10 +388,33 @@ __global__ __launch_bounds__(kSk1NT) void k_sk_part1(SkReads S, SkParams P, uint
         if (a > 0) hdr |= (1u << 13) | (base_at(rw, a - 1u) << 14);
         if (a + nb < len) hdr |= (1u << 16) | (base_at(rw, a + nb) << 17);
         rec[RW - 1] |= (uint64_t)hdr << kSkHdrShift;
-        const uint64_t dst = ((uint64_t)b1 * P.slot1 + g + rank) * RW;
+        uint64_t *dst;
+        if (g & 0x80000000u) {
+            const uint32_t *o = ovf[g & 63u];
+            dst = rank < o[1] ? out + ((uint64_t)b1 * P.slot1 + o[0] + rank) * RW : spill + ((uint64_t)o[2] + (rank - o[1])) * RW;
+        } else {
+            dst = out + ((uint64_t)b1 * P.slot1 + g + rank) * RW;
+        }
 #pragma unroll
-        for (int j = 0; j < RW; ++j) out[dst + j] = rec[j];
+        for (int j = 0; j < RW; ++j) dst[j] = rec[j];
     }
+}
+
+// the buckets spilled records belong to: all their records must take the k-mer path together
+template <int RW>
+__global__ __launch_bounds__(256) void k_sk_mark_hot(const uint64_t *__restrict__ spill, uint32_t n, SkParams P,
+                                                     uint8_t *__restrict__ hot, uint32_t *__restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t rec[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) rec[j] = spill[(uint64_t)i * RW + j];
+    uint32_t gp;
+    if (!sk_select(sk_g(sk_rec_hash<RW>(rec, P.m)), P, gp)) {
+        flags[SKF_SELECT] = 1u;
+        return;
+    }
+    hot[(size_t)sk_bin1(gp, P) * P.P2 + sk_bin2(gp, P)] = 1;
 }
 
 // ---- level 2: records of a level-1 slot -> dense buckets (exact: histogram, scan, scatter) ------------------------
@@ -496,6 +554,15 @@ __device__ __forceinline__ uint64_t sk_rec_bases(const uint64_t *rp, uint32_t p)
     return (lo >> sh) | ((hi << 1) << (63u - sh));
 }
 
+// a bucket this geometry cannot finish is listed: first geometry -> counter SKF_NFAIL (second chance); second geometry
+// -> counter SKF_NFAIL2 (the k-mer path)
+__device__ __forceinline__ void sk_give_up(uint32_t *flags, uint32_t *fail_list, uint32_t fail_ctr, uint32_t b, uint32_t nrec) {
+    const uint32_t at = atomicAdd(&flags[fail_ctr], 1u);
+    if (at < kSkdFailCap) fail_list[at] = b;
+    else if (fail_ctr == SKF_NFAIL2) flags[SKF_TABLE] = 1u;
+    atomicMax(&flags[SKF_MAXREC], nrec);
+}
+
 // LDS: recs[KEEP + STG][RW] u64 | ioff[STG + 2] | newidx[STG] | table[TS] | tvals[TS] (OP) | tmp[64] | work[STG * ipr] u16
 template <int W, int OP, class G>
 static size_t sk_dedup_smem(uint32_t C) {
@@ -517,7 +584,8 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
                                                     unsigned long long *__restrict__ out_cursor,
                                                     unsigned long long out_cap, uint32_t *__restrict__ flags,
                                                     const uint32_t *__restrict__ bucket_ids,
-                                                    uint32_t *__restrict__ fail_list) {
+                                                    uint32_t *__restrict__ fail_list, uint32_t fail_ctr,
+                                                    const uint8_t *__restrict__ hot) {
     constexpr int RW = W + 1, NT = GEO::NT, TS = GEO::TS, KEEP = GEO::KEEP, STG = GEO::NT, SR = kSkdSR;
     constexpr uint32_t EMPTY = 0xFFFFFFFFu;
     static_assert(KEEP + STG <= 2048 && STG <= 4096, "entry / work item bit fields");
@@ -532,6 +600,10 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = bucket_ids ? bucket_ids[blockIdx.x] : blockIdx.x;
     const unsigned long long r_begin = boff[b], r_end = boff[b + 1];
+    if (hot && hot[b]) {  // a record of this bucket sits in the spill list (its slot may even be empty here)
+        if (tid == 0) sk_give_up(flags, fail_list, fail_ctr, b, (uint32_t)(r_end - r_begin));
+        return;
+    }
     if (r_begin == r_end) return;
     const uint32_t k = P.k;
     for (uint32_t i = tid; i < (uint32_t)TS; i += NT) {
@@ -670,15 +742,7 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
             keep += tot;
         }
         if (__syncthreads_or(failed)) {  // nothing of this bucket has been written
-            if (tid == 0) {
-                if (fail_list) {
-                    const uint32_t at = atomicAdd(&flags[SKF_NFAIL], 1u);
-                    if (at < kSkdFailCap) fail_list[at] = b;
-                } else {
-                    atomicAdd(&flags[SKF_TABLE], 1u);
-                }
-                atomicMax(&flags[SKF_MAXREC], (uint32_t)(r_end - r_begin));
-            }
+            if (tid == 0) sk_give_up(flags, fail_list, fail_ctr, b, (uint32_t)(r_end - r_begin));
             return;
         }
     }
@@ -724,7 +788,64 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
     }
 }
 
+// Records the tables could not take (hot buckets, spill list) -> one canonical k-mer (+ edge mask) per instance, for
+// the k-mer path's dedup.  bucket_ids != null: one workgroup per listed bucket; else `n_flat` records of a flat list.
+template <int W, int OP>
+__global__ __launch_bounds__(256) void k_sk_expand(const uint64_t *__restrict__ records,
+                                                   const unsigned long long *__restrict__ boff,
+                                                   const uint32_t *__restrict__ bucket_ids, uint32_t n_flat, SkParams P,
+                                                   Key<W> *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                   unsigned long long *__restrict__ cursor, unsigned long long cap,
+                                                   uint32_t *__restrict__ flags) {
+    constexpr int RW = W + 1;
+    unsigned long long r0, r1, stride;
+    if (bucket_ids) {
+        const uint32_t b = bucket_ids[blockIdx.x];
+        r0 = boff[b] + threadIdx.x;
+        r1 = boff[b + 1];
+        stride = blockDim.x;
+    } else {
+        r0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+        r1 = n_flat;
+        stride = (unsigned long long)gridDim.x * blockDim.x;
+    }
+    const uint32_t k = P.k;
+    for (unsigned long long r = r0; r < r1; r += stride) {
+        const uint64_t *rp = records + r * RW;
+        const uint32_t hdr = (uint32_t)(rp[RW - 1] >> kSkHdrShift);
+        const uint32_t n = (hdr & 63u) + 1u;
+        const unsigned long long base = atomicAdd(cursor, (unsigned long long)n);
+        if (base + n > cap) {
+            flags[SKF_OUT] = 1u;
+            continue;
+        }
+        for (uint32_t j = 0; j < n; ++j) {
+            const Key<W> F = sk_kmer_at<W, RW>(rp, j, k);
+            const Key<W> RC = kmer_rc<W>(F, (int)k);
+            const bool minimal = sk_minimal<W>(F, RC);
+            key_store<W>(&keys[base + j], key_select<W>(minimal, F, RC));
+            if (OP == 3) {
+                const bool hp = j > 0 || ((hdr >> 13) & 1u), hn = j + 1u < n || ((hdr >> 16) & 1u);
+                const uint32_t prevc = j > 0 ? sk_base_at(rp, j - 1u) : (hdr >> 14) & 3u;
+                const uint32_t nextc = j + 1u < n ? sk_base_at(rp, j + k) : (hdr >> 17) & 3u;
+                uint32_t val = 0;
+                if (hn) val |= 1u << (minimal ? nextc : 7u - nextc);
+                if (hp) val |= 1u << (minimal ? 4u + prevc : 3u - prevc);
+                vals[base + j] = val;
+            }
+        }
+    }
+}
+
+__global__ void k_sk_sum_buckets(const uint32_t *__restrict__ ids, uint32_t n, const unsigned long long *__restrict__ boff,
+                                 unsigned long long *__restrict__ total) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(total, boff[ids[i] + 1] - boff[ids[i]]);
+}
+
 struct SkDedupArgs {
+    const uint8_t *hot;
+    uint32_t *fail2_list;
     const uint64_t *records;
     const unsigned long long *boff;
     void *out_keys;
@@ -737,14 +858,14 @@ struct SkDedupArgs {
 
 template <int W, int OP, class G>
 void launch_dedup_g(bbk_ctx *ctx, const char *fam, uint32_t nblocks, const SkParams &P, const SkDedupArgs &A,
-                    const uint32_t *bucket_ids, uint32_t *fail_list, double bytes) {
+                    const uint32_t *bucket_ids, uint32_t *fail_list, uint32_t fail_ctr, double bytes) {
     if (nblocks == 0) return;
     const size_t sm = sk_dedup_smem<W, OP, G>(P.C);
     auto fn = k_sk_dedup<W, OP, G>;
     BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     KernelTimer t(ctx, fam, bytes);
     hipLaunchKernelGGL(fn, dim3(nblocks), dim3(G::NT), sm, ctx->stream, A.records, A.boff, P, (Key<W> *)A.out_keys, A.out_vals,
-                       A.out_cursor, (unsigned long long)A.out_cap, A.flags, bucket_ids, fail_list);
+                       A.out_cursor, (unsigned long long)A.out_cap, A.flags, bucket_ids, fail_list, fail_ctr, A.hot);
     check_launch("k_sk_dedup");
 }
 
@@ -753,8 +874,8 @@ template <int W>
 void launch_dedup(bbk_ctx *ctx, int op, uint32_t nbuckets, uint32_t second, const SkParams &P, const SkDedupArgs &A, double bytes) {
     const char *fam = second ? "sk_dedup2" : "sk_dedup";
 #define BBK_SK_DEDUP(OPV)                                                                                    \
-    if (second) launch_dedup_g<W, OPV, SkdB>(ctx, fam, second, P, A, A.fail_list, nullptr, bytes);          \
-    else launch_dedup_g<W, OPV, SkdA>(ctx, fam, nbuckets, P, A, nullptr, A.fail_list, bytes)
+    if (second) launch_dedup_g<W, OPV, SkdB>(ctx, fam, second, P, A, A.fail_list, A.fail2_list, (uint32_t)SKF_NFAIL2, bytes); \
+    else launch_dedup_g<W, OPV, SkdA>(ctx, fam, nbuckets, P, A, nullptr, A.fail_list, (uint32_t)SKF_NFAIL, bytes)
     switch (op) {
         case MSD_OP_NONE: BBK_SK_DEDUP(0); break;
         case MSD_OP_COUNT: BBK_SK_DEDUP(1); break;
@@ -819,7 +940,8 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     const uint32_t P1 = 1u << b1bits;
     const uint32_t P2 = (uint32_t)std::min<double>(kSkMaxP2, std::max(1.0, std::ceil(nbp / P1)));
     const double est_pass = est_total / np;
-    const uint64_t slot1_64 = (uint64_t)(est_pass / P1 * 1.12) + 4096;
+    const char *es1 = getenv("BBK_SUPERK_SLOT_SCALE");  // tests: slots below the load, so that records spill
+    const uint64_t slot1_64 = (uint64_t)(est_pass / P1 * 1.12 * (es1 ? atof(es1) : 1.0)) + (es1 ? 16 : 4096);
     if (slot1_64 >= (1ull << 31)) return false;
     SkParams P{};
     P.k = k;
@@ -832,6 +954,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     P.P2 = P2;
     P.slot1 = (uint32_t)slot1_64;
     P.tps = (P.slot1 + kSk2Tile - 1) / kSk2Tile;
+    P.spill_cap = (uint32_t)std::min<double>(2.0e9, es1 ? est_pass + 65536.0 : est_pass / 8 + 65536.0);
     const uint64_t nbuckets = (uint64_t)P1 * P2;
     if ((uint64_t)P1 * P.tps >= (1ull << 31)) return false;
     const size_t sm1 = sk_part1_smem(C, P1, RW);
@@ -854,7 +977,12 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     const size_t rec_bytes = (size_t)RW * 8;
     DevBuf buf1((size_t)P1 * P.slot1 * rec_bytes), buf2;
     DevBuf cur1((size_t)P1 * 4 + 16), boff((size_t)(nbuckets + 1) * 8 + 16), cur2((size_t)nbuckets * 8 + 16), dflags(64),
-        dcursor(16), fail_list((size_t)kSkdFailCap * 4);
+        dcursor(16), fail_list((size_t)kSkdFailCap * 4), fail2_list((size_t)kSkdFailCap * 4), hot, fb_total(16);
+    DevBuf spill((size_t)P.spill_cap * rec_bytes + 16);
+    // share of the instances the k-mer path may have to take over (hot buckets, spilled records) before the whole batch
+    // is handed to it instead
+    const char *efm = getenv("BBK_SUPERK_FALLBACK_MAX");
+    const double fallback_max = efm ? atof(efm) : 0.25;
     BBK_HIP(hipMemsetAsync(dflags.p, 0, 64, ctx->stream));
     BBK_HIP(hipMemsetAsync(dcursor.p, 0, 16, ctx->stream));
 
@@ -877,22 +1005,26 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     uint32_t hflags[16];
     unsigned long long done_before = 0;
     auto declined = [&](uint32_t pass) {
-        BBK_REQUIRE(!hflags[SKF_SELECT], BBK_ERR_INTERNAL, "superk: a record arrived in a bin its hash does not name");
+        // (after a level-1 overflow the slots have holes: level 2 may then have met anything)
+        BBK_REQUIRE(!hflags[SKF_SELECT] || hflags[SKF_SLOT1], BBK_ERR_INTERNAL,
+                    "superk: a record arrived in a bin its hash does not name");
         if (verbose)
-            fprintf(stderr, "[bbk] superk declines (pass %u): slot1=%u first-chance failures=%u second-chance failures=%u, largest %u records\n",
-                    pass, hflags[SKF_SLOT1], hflags[SKF_NFAIL], hflags[SKF_TABLE], hflags[SKF_MAXREC]);
+            fprintf(stderr, "[bbk] superk declines (pass %u): level-1 overflow=%u, buckets to the second chance=%u, to the k-mer path=%u (list full=%u), spilled records=%u, largest bucket %u records\n",
+                    pass, hflags[SKF_SLOT1], hflags[SKF_NFAIL], hflags[SKF_NFAIL2], hflags[SKF_TABLE], hflags[SKF_NSPILL],
+                    hflags[SKF_MAXREC]);
         ctx->add_stat("stat_superk_declined", 1);
         ctx->superk_dup = 0;
         return false;
     };
     for (uint32_t pass = 0; pass < np; ++pass) {
         P.pass = pass;
+        BBK_HIP(hipMemsetAsync(dflags.p, 0, 64, ctx->stream));
         BBK_HIP(hipMemsetAsync(cur1.p, 0, (size_t)P1 * 4, ctx->stream));
         BBK_HIP(hipMemsetAsync(boff.p, 0, (size_t)(nbuckets + 1) * 8, ctx->stream));
         {
             KernelTimer t(ctx, "sk_part1", (double)rd->n_words * 8 + est_pass * rec_bytes);
             hipLaunchKernelGGL(k_sk_part1<RW>, dim3((unsigned)ntiles1), dim3(kSk1NT), sm1, ctx->stream, S, P, cur1.as<uint32_t>(),
-                               buf1.as<uint64_t>(), dflags.as<uint32_t>());
+                               buf1.as<uint64_t>(), spill.as<uint64_t>(), dflags.as<uint32_t>());
             check_launch("k_sk_part1");
         }
         {
@@ -904,9 +1036,19 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
         const uint64_t n_rec = exclusive_scan_u64(ctx, boff.as<uint64_t>(), boff.as<uint64_t>(), nbuckets);
         BBK_HIP(hipMemcpyAsync(boff.as<uint64_t>() + nbuckets, &n_rec, 8, hipMemcpyHostToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(cur2.p, boff.p, (size_t)nbuckets * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        BBK_HIP(hipMemcpyAsync(hflags, dflags.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(hflags, dflags.p, 64, hipMemcpyDeviceToHost, ctx->stream));
         BBK_HIP(hipStreamSynchronize(ctx->stream));  // n_rec is a stack variable; level-1 flags
         if (hflags[SKF_SLOT1] || hflags[SKF_STAGE] || hflags[SKF_SELECT]) return declined(pass);
+        const uint32_t n_spill = hflags[SKF_NSPILL];
+        if (n_spill) {  // hot minimizers: the buckets of the spilled records go to the k-mer path as a whole
+            if (!hot.p) hot.alloc((size_t)nbuckets + 16);
+            BBK_HIP(hipMemsetAsync(hot.p, 0, (size_t)nbuckets, ctx->stream));
+            hipLaunchKernelGGL(k_sk_mark_hot<RW>, dim3((n_spill + 255) / 256), dim3(256), 0, ctx->stream, spill.as<uint64_t>(),
+                               n_spill, P, hot.as<uint8_t>(), dflags.as<uint32_t>());
+            check_launch("k_sk_mark_hot");
+            if (verbose) fprintf(stderr, "[bbk] superk: %u records spilled from full level-1 slots\n", n_spill);
+            ctx->add_stat("stat_superk_spilled", (double)n_spill);
+        }
         if (buf2.bytes < (n_rec + 1) * rec_bytes) {
             buf2.release();
             buf2.alloc((size_t)((double)(n_rec + 1) * (np > 1 ? 1.05 : 1.0)) * rec_bytes);
@@ -922,12 +1064,14 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
             // algorithmic bytes: the records read + the distinct keys written (their number is only known afterwards:
             // the planning multiplicity stands in)
             const double db = (double)n_rec * rec_bytes + (double)N / np / dup_plan * (key_bytes + (op != MSD_OP_NONE ? 4 : 0));
-            SkDedupArgs A{buf2.as<uint64_t>(), boff.as<unsigned long long>(), okeys.p, ovals.as<uint32_t>(),
-                          dcursor.as<unsigned long long>(), out_cap, dflags.as<uint32_t>(), fail_list.as<uint32_t>()};
+            SkDedupArgs A{n_spill ? hot.as<uint8_t>() : nullptr, fail2_list.as<uint32_t>(), buf2.as<uint64_t>(),
+                          boff.as<unsigned long long>(), okeys.p, ovals.as<uint32_t>(), dcursor.as<unsigned long long>(), out_cap,
+                          dflags.as<uint32_t>(), fail_list.as<uint32_t>()};
             BBK_HIP(hipMemsetAsync(dflags.as<uint32_t>() + SKF_NFAIL, 0, 4, ctx->stream));
+            BBK_HIP(hipMemsetAsync(dflags.as<uint32_t>() + SKF_NFAIL2, 0, 4, ctx->stream));
             launch_dedup<W>(ctx, op, (uint32_t)nbuckets, 0, P, A, db);
             unsigned long long cursor_now = 0;
-            BBK_HIP(hipMemcpyAsync(hflags, dflags.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+            BBK_HIP(hipMemcpyAsync(hflags, dflags.p, 64, hipMemcpyDeviceToHost, ctx->stream));
             BBK_HIP(hipMemcpyAsync(&cursor_now, dcursor.p, 8, hipMemcpyDeviceToHost, ctx->stream));
             BBK_HIP(hipStreamSynchronize(ctx->stream));
             if (hflags[SKF_NFAIL] && !hflags[SKF_OUT]) {  // second chance for the buckets the small table gave up
@@ -937,11 +1081,87 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
                             hflags[SKF_MAXREC]);
                 ctx->add_stat("stat_superk_second_chance", (double)hflags[SKF_NFAIL]);
                 launch_dedup<W>(ctx, op, (uint32_t)nbuckets, hflags[SKF_NFAIL], P, A, 0);
-                BBK_HIP(hipMemcpyAsync(hflags, dflags.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+                BBK_HIP(hipMemcpyAsync(hflags, dflags.p, 64, hipMemcpyDeviceToHost, ctx->stream));
                 BBK_HIP(hipMemcpyAsync(&cursor_now, dcursor.p, 8, hipMemcpyDeviceToHost, ctx->stream));
                 BBK_HIP(hipStreamSynchronize(ctx->stream));
             }
             if (hflags[SKF_TABLE] || hflags[SKF_SELECT]) return declined(pass);
+            const uint32_t n_fail2 = hflags[SKF_NFAIL2];
+            if (!hflags[SKF_OUT] && (n_fail2 || n_spill)) {
+                // What the tables could not take -- buckets with more distinct keys than the second-chance table holds
+                // (one low-complexity minimizer shared by thousands of k-mers) and the buckets of spilled records -- is
+                // expanded into one key per instance and deduplicated by the k-mer path; the keys of a bucket occur in
+                // no other bucket, so the distinct records are simply appended.
+                unsigned long long fb_rec = 0;
+                BBK_HIP(hipMemsetAsync(fb_total.p, 0, 16, ctx->stream));
+                if (n_fail2) {
+                    hipLaunchKernelGGL(k_sk_sum_buckets, dim3((n_fail2 + 255) / 256), dim3(256), 0, ctx->stream,
+                                       fail2_list.as<uint32_t>(), n_fail2, boff.as<unsigned long long>(),
+                                       fb_total.as<unsigned long long>());
+                    check_launch("k_sk_sum_buckets");
+                }
+                BBK_HIP(hipMemcpyAsync(&fb_rec, fb_total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+                BBK_HIP(hipStreamSynchronize(ctx->stream));
+                fb_rec += n_spill;
+                const uint64_t inst_ub = fb_rec * (uint64_t)C;
+                if (verbose)
+                    fprintf(stderr, "[bbk] superk: %u buckets (largest %u records) + %u spilled records = %llu records to the k-mer path\n",
+                            n_fail2, hflags[SKF_MAXREC], n_spill, fb_rec);
+                if ((double)inst_ub > fallback_max * (double)N / np + 65536.0) return declined(pass);
+                ctx->add_stat("stat_superk_kmer_path_records", (double)fb_rec);
+                DevBuf fk(inst_ub * key_bytes + 16), fv;
+                if (op == MSD_OP_OR) fv.alloc(inst_ub * 4 + 16);
+                BBK_HIP(hipMemsetAsync(fb_total.p, 0, 16, ctx->stream));
+                auto expand = [&](const uint64_t *recs, const uint32_t *ids, uint32_t nblocks, uint32_t n_flat) {
+                    if (nblocks == 0) return;
+                    KernelTimer t(ctx, "sk_expand", 0);
+                    if (op == MSD_OP_OR)
+                        hipLaunchKernelGGL((k_sk_expand<W, 3>), dim3(nblocks), dim3(256), 0, ctx->stream, recs, boff.as<unsigned long long>(),
+                                           ids, n_flat, P, fk.as<Key<W>>(), fv.as<uint32_t>(), fb_total.as<unsigned long long>(),
+                                           (unsigned long long)inst_ub, dflags.as<uint32_t>());
+                    else
+                        hipLaunchKernelGGL((k_sk_expand<W, 0>), dim3(nblocks), dim3(256), 0, ctx->stream, recs, boff.as<unsigned long long>(),
+                                           ids, n_flat, P, fk.as<Key<W>>(), (uint32_t *)nullptr, fb_total.as<unsigned long long>(),
+                                           (unsigned long long)inst_ub, dflags.as<uint32_t>());
+                    check_launch("k_sk_expand");
+                };
+                expand(buf2.as<uint64_t>(), fail2_list.as<uint32_t>(), n_fail2, 0);
+                expand(spill.as<uint64_t>(), nullptr, n_spill ? std::min<uint32_t>((n_spill + 255) / 256, 65536u) : 0u, n_spill);
+                unsigned long long fb_inst = 0;
+                BBK_HIP(hipMemcpyAsync(&fb_inst, fb_total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+                BBK_HIP(hipMemcpyAsync(hflags, dflags.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+                BBK_HIP(hipStreamSynchronize(ctx->stream));
+                BBK_REQUIRE(!hflags[SKF_OUT] && fb_inst <= inst_ub, BBK_ERR_INTERNAL, "superk: expansion ran over its bound");
+                MsdOutput mo;
+                if (!msd_sort_reduce(ctx, k, MSD_HASH, op, nullptr, fk.p, op == MSD_OP_OR ? fv.as<uint32_t>() : nullptr, fb_inst,
+                                     false, mo))
+                    return declined(pass);
+                fk.release();
+                fv.release();
+                if (cursor_now + mo.n > out_cap) {  // room for the appended records
+                    const uint64_t new_cap = cursor_now + mo.n + (N - std::min<uint64_t>(N, cursor_now + mo.n)) / 8;
+                    DevBuf nkeys(new_cap * key_bytes + 16), nvals;
+                    BBK_HIP(hipMemcpyAsync(nkeys.p, okeys.p, cursor_now * key_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    if (op != MSD_OP_NONE) {
+                        nvals.alloc(new_cap * 4 + 16);
+                        BBK_HIP(hipMemcpyAsync(nvals.p, ovals.p, cursor_now * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                    }
+                    BBK_HIP(hipStreamSynchronize(ctx->stream));
+                    okeys = std::move(nkeys);
+                    if (op != MSD_OP_NONE) ovals = std::move(nvals);
+                    out_cap = new_cap;
+                }
+                if (mo.n) {
+                    BBK_HIP(hipMemcpyAsync(okeys.as<char>() + cursor_now * key_bytes, mo.keys.p, mo.n * key_bytes,
+                                           hipMemcpyDeviceToDevice, ctx->stream));
+                    if (op != MSD_OP_NONE)
+                        BBK_HIP(hipMemcpyAsync(ovals.as<uint32_t>() + cursor_now, mo.vals.p, mo.n * 4, hipMemcpyDeviceToDevice,
+                                               ctx->stream));
+                }
+                cursor_now += mo.n;
+                BBK_HIP(hipMemcpyAsync(dcursor.p, &cursor_now, 8, hipMemcpyHostToDevice, ctx->stream));
+                BBK_HIP(hipStreamSynchronize(ctx->stream));  // cursor_now is a stack variable; mo's buffers are about to go
+            }
             if (!hflags[SKF_OUT]) {
                 done_before = cursor_now;
                 break;

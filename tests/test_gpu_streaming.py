@@ -217,3 +217,72 @@ def test_superk_gives_up_and_the_kmer_path_takes_over():
     err = _run({"BBK_MERGE_MIN": "0", "BBK_SUPERK_MIN": "0", "BBK_SUPERK_FILL": "64"}, 2500, 15000, (55,))
     lines = _superk_lines(err)
     assert any("declines" in l for l in lines), lines[:5]
+
+
+def test_superk_spilled_slots_and_hot_buckets_take_the_kmer_path():
+    """level-1 slots far below their load: the records that do not fit go to the spill list, the buckets they belong
+    to are marked hot and skipped by both tables, and everything of those buckets (slot part + spilled part) is expanded
+    into k-mers and deduplicated by the k-mer path, then appended -- the batch is NOT given up (the allowance for the
+    k-mer path's share is lifted for the test)"""
+    err = _run({"BBK_MERGE_MIN": "0", "BBK_SUPERK_MIN": "0", "BBK_SUPERK_SLOT_SCALE": "0.12", "BBK_SUPERK_FALLBACK_MAX": "4"},
+               2500, 15000, (55, 77, 127))
+    lines = _superk_lines(err)
+    assert any("spilled from full level-1 slots" in l for l in lines), lines[:5]
+    assert any("records to the k-mer path" in l for l in lines), lines[:5]
+    assert not any("declines" in l for l in lines), [l for l in lines if "declines" in l][:3]
+
+
+def test_superk_buckets_beyond_both_tables_take_the_kmer_path():
+    """buckets planned 8x over the first table: most of them overflow the second-chance table too and are finished by
+    the k-mer path, bucket by bucket"""
+    err = _run({"BBK_MERGE_MIN": "0", "BBK_SUPERK_MIN": "0", "BBK_SUPERK_FILL": "8", "BBK_SUPERK_FALLBACK_MAX": "4"},
+               2500, 15000, (55, 96))
+    lines = _superk_lines(err)
+    assert any("records to the k-mer path" in l and " 0 spilled" in l for l in lines), lines[:5]
+    assert not any("declines" in l for l in lines), [l for l in lines if "declines" in l][:3]
+
+
+def test_superk_low_complexity_reads(monkeypatch, capfd):
+    """250 k reads of a random genome + 50 k reads that share a 35 bp poly-A stretch between random flanks: the
+    poly-A 24-mer is the minimizer of ~a million distinct 55-mers -- one level-1 slot runs over (spill list), one bucket
+    is far beyond both tables.  Default thresholds: the batch must not be given up, the hot bucket goes to the k-mer
+    path, and the result equals the k-mer path's (BBK_NO_SUPERK=1) element by element."""
+    import random
+    import torch
+    import spades_for_blackbird_amd as B
+    rnd = random.Random(5)
+    genome = "".join(rnd.choice("ACGT") for _ in range(1_500_000))
+    reads = []
+    for _ in range(250_000):
+        p = rnd.randrange(len(genome) - 150)
+        reads.append(genome[p:p + 150])
+    for _ in range(50_000):
+        reads.append("".join(rnd.choice("ACGT") for _ in range(40)) + "A" * 35 + "".join(rnd.choice("ACGT") for _ in range(75)))
+    rnd.shuffle(reads)
+    k, W = 55, 2
+    ctx = B.Context(0, stream=torch.cuda.current_stream())
+    r = ctx.reads_from_ascii(reads)
+    monkeypatch.setenv("BBK_VERBOSE", "1")
+
+    def run():
+        s = ctx.count(r, k, B.CANONICAL | B.WITH_COUNTS)
+        keys = torch.empty((len(s), W), dtype=torch.int64, device="cuda")
+        cnt = torch.empty(len(s), dtype=torch.int32, device="cuda")
+        s.export_to(keys, B.ORDER_SORTED, cnt)
+        x = ctx.extindex(r, k)
+        xk = torch.empty((len(x), W), dtype=torch.int64, device="cuda")
+        xm = torch.empty(len(x), dtype=torch.int32, device="cuda")
+        x.export_to_u32(xk, xm)
+        return keys, cnt, xk, xm
+
+    a = run()
+    err = capfd.readouterr().err
+    lines = [l for l in err.splitlines() if "superk" in l]
+    assert any("records to the k-mer path" in l for l in lines), lines[:6]
+    assert not any("declines" in l for l in lines), [l for l in lines if "declines" in l][:3]
+    monkeypatch.setenv("BBK_NO_SUPERK", "1")
+    b = run()
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and bool(torch.equal(x, y))
+    assert int(a[1].sum(dtype=torch.int64).item()) == len(reads) * (150 - k + 1)
+    ctx.close()
