@@ -312,14 +312,41 @@ bool Accum::has_vals() const { return with_mask || want_vals; }
 int Accum::merge_op() const { return with_mask ? MSD_OP_OR : (want_vals ? MSD_OP_SUM : MSD_OP_NONE); }
 
 void Accum::push(const bbk_reads *rd) {
-    Run r;
-    uint64_t inst = 0;
-    dedup_reads(ctx, rd, k, with_mask, want_vals, r.keys, r.vals, r.n, inst);
-    instances += inst;
+    auto one = [&](const bbk_reads *part) {
+        Run r;
+        uint64_t inst = 0;
+        dedup_reads(ctx, part, k, with_mask, want_vals, r.keys, r.vals, r.n, inst);
+        instances += inst;
+        if (r.n == 0) return;
+        runs_n += r.n;
+        runs.push_back(std::move(r));
+    };
+    // 8-byte keys: one call above one pass of stage A (1.6 G instances with narrow records) would run in hash ranges,
+    // and every range re-extracts every k-mer of the reads (100 M x 150 bp, k = 21: 7 ranges, 525 of 615 ms).  The
+    // reads are cut into pieces of one pass each instead -- what a caller that pushes blocks gets anyway -- and the runs
+    // are merged once.  (Wider keys go through super-k-mer records, which never re-extract.)
+    const char *ec = getenv("BBK_READ_CHUNK");  // tests: bases per piece
+    const uint64_t piece = ec ? strtoull(ec, nullptr, 10) : 1500000000ull;
+    if (words_of(k) == 1 && rd->n >= 2 && rd->bases > piece && msd_enabled()) {
+        const uint64_t np = (rd->bases + piece - 1) / piece, per = (rd->n + np - 1) / np;
+        if (getenv("BBK_VERBOSE"))
+            fprintf(stderr, "[bbk] count: %llu reads in %llu pieces of %llu\n", (unsigned long long)rd->n,
+                    (unsigned long long)((rd->n + per - 1) / per), (unsigned long long)per);
+        for (uint64_t r0 = 0; r0 < rd->n; r0 += per) {
+            bbk_reads v;  // a view: owns nothing
+            v.ctx = rd->ctx;
+            v.n = std::min<uint64_t>(per, rd->n - r0);
+            v.n_words = rd->n_words;
+            v.bases = (uint64_t)((double)rd->bases * (double)v.n / (double)rd->n);
+            v.d_words = rd->d_words;
+            v.d_woff = rd->d_woff + r0;
+            v.d_len = rd->d_len + r0;
+            one(&v);
+        }
+    } else {
+        one(rd);
+    }
     ++batches;
-    if (r.n == 0) return;
-    runs_n += r.n;
-    runs.push_back(std::move(r));
     static const char *e = getenv("BBK_MERGE_MIN");  // tests force a merge after every push
     const uint64_t floor_n = e ? strtoull(e, nullptr, 10) : (32ull << 20);
     if ((runs.size() > 1 || n) && runs_n >= n / 2 + floor_n) merge();

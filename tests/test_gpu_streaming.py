@@ -286,3 +286,10 @@ def test_superk_low_complexity_reads(monkeypatch, capfd):
         assert x.shape == y.shape and bool(torch.equal(x, y))
     assert int(a[1].sum(dtype=torch.int64).item()) == len(reads) * (150 - k + 1)
     ctx.close()
+
+
+def test_one_call_is_cut_into_read_pieces():
+    """8-byte keys: a call above one stage-A pass is cut into pieces of reads (each deduplicated on its own, merged
+    once) instead of hash ranges that re-extract every k-mer per range; forced here with 60 k bases per piece"""
+    err = _run({"BBK_READ_CHUNK": "60000"}, 2500, 15000, (16, 21, 31, 32))
+    assert "pieces of" in err
