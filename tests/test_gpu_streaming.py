@@ -163,8 +163,8 @@ def test_superk_second_chance_table():
     assert not any("declines" in l for l in lines), lines[:5]
 
 
-@pytest.mark.parametrize("k", [55, 77])
-def test_superk_equals_kmer_path_at_size(k, monkeypatch):
+@pytest.mark.parametrize("k,meta", [(55, False), (77, False), (55, True), (33, True)])
+def test_superk_equals_kmer_path_at_size(k, meta, monkeypatch):
     """3 M x 150 bp (0.29 G instances: the super-k-mer path's default threshold is 4 M, its buckets, slots and tables are
     the planned sizes, several thousand buckets go through the second chance with a second batch planned for the first
     one's multiplicity): the canonical set with multiplicities and the extension index (keys + edge masks) must be
@@ -173,7 +173,10 @@ def test_superk_equals_kmer_path_at_size(k, monkeypatch):
     import spades_for_blackbird_amd as B
     ctx = B.Context(0, stream=torch.cuda.current_stream())
     n_reads, L = 3_000_000, 150
-    r = ctx.reads_synth(n_reads, read_len=L, genome_len=n_reads * L // 20, seed_genome=7, seed_reads=8)
+    if meta:  # the skewed metagenome of BASELINE configs[4]: 200 genomes, log-normal abundances (coverage 0.01x .. 1000x)
+        r = ctx.reads_synth_meta(n_reads, read_len=L)
+    else:
+        r = ctx.reads_synth(n_reads, read_len=L, genome_len=n_reads * L // 20, seed_genome=7, seed_reads=8)
     W = (k + 31) // 32
 
     def run():
