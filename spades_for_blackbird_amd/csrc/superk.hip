@@ -485,19 +485,26 @@ __global__ __launch_bounds__(kSk2NT) void k_sk_part2(const uint64_t *__restrict_
 // k-mer starting at base j of a record in LDS (RW words at rp)
 template <int W, int RW>
 __device__ __forceinline__ Key<W> sk_kmer_at(const uint64_t *rp, uint32_t j, uint32_t k) {
-    const uint32_t wi = j >> 5, sh = (j & 31u) << 1;
-    uint64_t x[W + 1];
+    // the bit field starts at bit 2j: whole dwords by addressing, the rest by 32-bit funnel shifts (v_alignbit_b32);
+    // 64-bit shifts by a register amount run at a quarter of the rate and there were four per extraction
+    const uint32_t *rd = reinterpret_cast<const uint32_t *>(rp);
+    const uint32_t d0 = j >> 4, sh = (j & 15u) << 1;  // dword offset, bit shift 0..30
+    uint32_t x[2 * W + 1];
 #pragma unroll
-    for (int i = 0; i <= W; ++i) x[i] = (wi + (uint32_t)i < (uint32_t)RW) ? rp[wi + (uint32_t)i] : 0ull;
+    for (int i = 0; i <= 2 * W; ++i) x[i] = (d0 + (uint32_t)i < (uint32_t)(2 * RW)) ? rd[d0 + (uint32_t)i] : 0u;
     Key<W> r;
 #pragma unroll
-    for (int i = 0; i < W; ++i) r.w[i] = (x[i] >> sh) | ((x[i + 1] << 1) << (63u - sh));
+    for (int i = 0; i < W; ++i) {
+        const uint32_t lo = __builtin_amdgcn_alignbit(x[2 * i + 1], x[2 * i], sh);
+        const uint32_t hi = __builtin_amdgcn_alignbit(x[2 * i + 2], x[2 * i + 1], sh);
+        r.w[i] = ((uint64_t)hi << 32) | lo;
+    }
     const uint32_t vb = 2u * k - 64u * (uint32_t)(W - 1);  // populated bits of the last word (2..64)
     if (vb < 64u) r.w[W - 1] &= (1ull << vb) - 1ull;
     return r;
 }
 __device__ __forceinline__ uint32_t sk_base_at(const uint64_t *rp, uint32_t p) {
-    return (uint32_t)(rp[p >> 5] >> ((p & 31u) << 1)) & 3u;
+    return (reinterpret_cast<const uint32_t *>(rp)[p >> 4] >> ((p & 15u) << 1)) & 3u;
 }
 
 // append base c (drop base 0) to F and prepend its complement to RC (drop RC's last base)
@@ -548,10 +555,12 @@ __device__ __forceinline__ uint32_t sk_khash(const Key<W> &x) {
 // 32 bases of a record in LDS from base p on (bits past the record's last word read as zero)
 template <int RW>
 __device__ __forceinline__ uint64_t sk_rec_bases(const uint64_t *rp, uint32_t p) {
-    const uint32_t wi = p >> 5, sh = (p & 31u) << 1;
-    const uint64_t lo = wi < (uint32_t)RW ? rp[wi] : 0ull;
-    const uint64_t hi = wi + 1u < (uint32_t)RW ? rp[wi + 1u] : 0ull;
-    return (lo >> sh) | ((hi << 1) << (63u - sh));
+    const uint32_t *rd = reinterpret_cast<const uint32_t *>(rp);
+    const uint32_t d0 = p >> 4, sh = (p & 15u) << 1;
+    uint32_t x[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x[i] = (d0 + (uint32_t)i < (uint32_t)(2 * RW)) ? rd[d0 + (uint32_t)i] : 0u;
+    return ((uint64_t)__builtin_amdgcn_alignbit(x[2], x[1], sh) << 32) | __builtin_amdgcn_alignbit(x[1], x[0], sh);
 }
 
 // a bucket this geometry cannot finish is listed: first geometry -> counter SKF_NFAIL (second chance); second geometry
