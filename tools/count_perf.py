@@ -1,0 +1,23 @@
+"""One count (both strands, final_kmers order) of synthetic reads in a loop, with the HIP-event time of every kernel family:
+   python tools/count_perf.py <k> [reads]      (on the GPU box; BBK_NO_SUPERK=1 etc. select the A/B variants)"""
+import os, sys, time
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import spades_for_blackbird_amd as B
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 55
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+flags = B.BOTH_STRANDS | B.REFERENCE_ORDER
+ctx = B.Context(0)
+reads = ctx.reads_synth(n)
+for it in range(3):
+    s = ctx.count(reads, k, flags); ctx.synchronize(); nn = len(s); s.free()
+ctx.profile(True); ctx.profile_reset()
+t0 = time.time()
+R = 3
+for it in range(R):
+    s = ctx.count(reads, k, flags); ctx.synchronize(); s.free()
+dt = (time.time() - t0) / R
+print(f"k={k} n={n} distinct={nn} ms/step={dt*1e3:.2f}")
+fams = ["sk_part1", "sk_hist2", "sk_part2", "sk_dedup", "part_scatter1_reads", "part_scatter2", "lds_dedup", "part_scatter1_keys", "lds_sort", "part_hist1_keys", "part_hist2", "stat_superk_records", "stat_superk_declined"]
+for f in fams:
+    d = ctx.profile_get(f); ms, cnt, by = d["ms"], d["launches"], d["bytes"]
+    if cnt: print(f"  {f:24s} {ms/R:8.3f} ms/step  launches/step {cnt/R:5.1f}  bytes/step {by/R/1e9:8.3f} GB")
