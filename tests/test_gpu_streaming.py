@@ -296,3 +296,37 @@ def test_one_call_is_cut_into_read_pieces():
     once) instead of hash ranges that re-extract every k-mer per range; forced here with 60 k bases per piece"""
     err = _run({"BBK_READ_CHUNK": "60000"}, 2500, 15000, (16, 21, 31, 32))
     assert "pieces of" in err
+
+
+@pytest.mark.parametrize("k", [33, 55, 97])
+def test_superk_ragged_reads(k, monkeypatch, capfd):
+    """reads of very different lengths through the super-k-mer path: 20 kbp reads (hundreds of segments each, tiles that
+    lie inside one read), runs of reads shorter than k (no segment at all) between them, reads of exactly k and k+1
+    bases, a read that is one long homopolymer; counts and extension index against the oracle"""
+    import random
+    import numpy as np
+    import spades_for_blackbird_amd as B
+    from oracle import oracle as O
+    rnd = random.Random(k)
+    rs = lambda n: "".join(rnd.choice("ACGT") for _ in range(n))
+    long_reads = [rs(20_000) for _ in range(4)]
+    reads = []
+    for lr in long_reads:
+        reads.append(lr)
+        reads += [rs(rnd.randrange(1, k)) for _ in range(300)]           # no k-mer at all
+        reads += [lr[p:p + 150] for p in range(0, 19_000, 97)]            # overlap the long read: duplicates
+    reads += [rs(k), rs(k + 1), "C" * 700, "", "ACGTN" * 40, rs(5_000) + "N" + rs(30)]
+    monkeypatch.setenv("BBK_SUPERK_MIN", "0")
+    monkeypatch.setenv("BBK_VERBOSE", "1")
+    ctx = B.Context(0)
+    r = ctx.reads_from_ascii(reads)
+    exp, ec = O.kmercount(reads, k, 16, 2, with_counts=True)
+    got, gc = ctx.count(r, k, B.BOTH_STRANDS | B.WITH_COUNTS).export(B.ORDER_REFERENCE_BUCKETS16, with_counts=True)
+    assert np.array_equal(got, exp) and np.array_equal(gc, ec)
+    ox = O.ExtIndex(reads, k, 1)
+    order = np.lexsort([ox.kmers[:, j] for j in range(ox.kmers.shape[1] - 1, -1, -1)])
+    xk, xm = ctx.extindex(r, k).export()
+    assert np.array_equal(xk, ox.kmers[order]) and np.array_equal(xm, ox.masks[order])
+    err = capfd.readouterr().err
+    assert "superk:" in err and "distinct" in err and "declines" not in err
+    ctx.close()
