@@ -1220,24 +1220,33 @@ __global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_
 
 // ---- first-choice bucket kernel: ONE distribution pass instead of ballot-ranked radix passes.
 // The records of a bucket are spread evenly over its key range (KEYS/REF mode: a contiguous range of k-mers
-// of a genome), so kDistBins bins over the top bits of (word 0 - bucket minimum) hold about one record
+// of a genome), so DistBins::N bins over the top bits of (word 0 - bucket minimum) hold about one record
 // each: count with LDS atomics, scan, scatter with returning atomics (the order inside a bin is arbitrary),
 // then the owner of a bin puts it in order by insertion on the whole key.  A bin above kDistMaxBin (skewed
 // keys, a k-mer repeated hundreds of times in an unreduced stream) marks the bucket as overflowing and the
 // host hands it to k_bucket, which takes any distribution.
-constexpr int kDistBins = 4096;
+// 4096 bins; wide keys WITH a payload: 2048, so that keys + payloads + bins stay below 80 KB and TWO workgroups fit a CU
+// (16-byte keys: 57 + 14 + 8 KB).  With 4096 bins the sort of an extension index of 16-byte keys (k-mer + edge mask) ran
+// one workgroup per CU: 8.1 ms against 5.0 ms for 257 M records.  (8-byte keys with a payload stay at 4096 bins and
+// one workgroup per CU: with 5632 records per bucket the fuller bins cost more than the second workgroup gains.)
+template <int W, int OP>
+struct DistBins {
+    static constexpr int N = (W >= 2 && OP >= 2) ? 2048 : 4096;
+    static constexpr int LOG = (W >= 2 && OP >= 2) ? 11 : 12;
+};
 constexpr uint32_t kDistMaxBin = 96;  // equal keys insert in linear time; only distinct keys cost n^2
 
 template <int W, int NT, int ITEMS, int OP>
 __global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, uint32_t *__restrict__ vals, BucketArgs A) {
     constexpr int CAP = NT * ITEMS;
     constexpr int NWAVES = NT / 64;
-    constexpr int BPT = kDistBins / NT;
+    constexpr int DB = DistBins<W, OP>::N;
+    constexpr int BPT = DB / NT;
     constexpr bool IN_VAL = OP >= 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: bins[kDistBins] | scan[32] | mm[2 * NWAVES] (u64) | skeys[CAP] | svals[CAP] (IN_VAL)
+    // layout: bins[DB] | scan[32] | mm[2 * NWAVES] (u64) | skeys[CAP] | svals[CAP] (IN_VAL)
     uint32_t *bins = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *scan_tmp = bins + kDistBins;
+    uint32_t *scan_tmp = bins + DB;
     uint64_t *mm = reinterpret_cast<uint64_t *>(scan_tmp + 32);
     Key<W> *skeys = reinterpret_cast<Key<W> *>(mm + 2 * NWAVES);
     uint32_t *svals = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(skeys) + sizeof(Key<W>) * CAP);
@@ -1254,7 +1263,7 @@ __global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, ui
         if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
         return;
     }
-    for (uint32_t q = tid; q < (uint32_t)kDistBins; q += NT) bins[q] = 0;
+    for (uint32_t q = tid; q < (uint32_t)DB; q += NT) bins[q] = 0;
 #ifdef BBK_PHASE_PROF
     unsigned long long t_prev = clock64();
 #endif
@@ -1297,7 +1306,7 @@ __global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, ui
     BBK_PH(3, 0, t_prev);  // loads + min/max
     const uint64_t kmin = mn;
     const int rbits = 64 - __builtin_clzll((mx - mn) | 1ull);
-    const int sh = rbits > 12 ? rbits - 12 : 0;  // digit = (word 0 - min) >> sh < 4096
+    const int sh = rbits > DistBins<W, OP>::LOG ? rbits - DistBins<W, OP>::LOG : 0;  // digit = (word 0 - min) >> sh < bins
 
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -1464,7 +1473,7 @@ __global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, ui
 
 template <int W, int NT, int ITEMS, int OP>
 static size_t bucket_dist_smem() {
-    return sizeof(uint32_t) * (kDistBins + 32) + sizeof(uint64_t) * 2 * (NT / 64) + (size_t)W * 8 * NT * ITEMS +
+    return sizeof(uint32_t) * (DistBins<W, OP>::N + 32) + sizeof(uint64_t) * 2 * (NT / 64) + (size_t)W * 8 * NT * ITEMS +
            (OP >= 2 ? 4 * NT * ITEMS : 0);
 }
 

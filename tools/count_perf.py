@@ -6,15 +6,19 @@ import spades_for_blackbird_amd as B
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 55
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
 flags = B.BOTH_STRANDS | B.REFERENCE_ORDER
+if os.environ.get("WITH_COUNTS"): flags |= B.WITH_COUNTS
+EXT = bool(os.environ.get("EXT_INDEX"))  # time the extension index (edge masks) instead of the count
 ctx = B.Context(0)
 reads = ctx.reads_synth(n)
+def one():
+    return ctx.extindex(reads, k) if EXT else ctx.count(reads, k, flags)
 for it in range(3):
-    s = ctx.count(reads, k, flags); ctx.synchronize(); nn = len(s); s.free()
+    s = one(); ctx.synchronize(); nn = len(s); del s
 ctx.profile(True); ctx.profile_reset()
 t0 = time.time()
 R = 3
 for it in range(R):
-    s = ctx.count(reads, k, flags); ctx.synchronize(); s.free()
+    s = one(); ctx.synchronize(); del s
 dt = (time.time() - t0) / R
 print(f"k={k} n={n} distinct={nn} ms/step={dt*1e3:.2f}")
 fams = ["sk_part1", "sk_hist2", "sk_part2", "sk_dedup", "part_scatter1_reads", "part_scatter2", "lds_dedup", "part_scatter1_keys", "lds_sort", "part_hist1_keys", "part_hist2", "stat_superk_records", "stat_superk_declined"]
