@@ -1826,17 +1826,25 @@ __global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, uint64_t n, 
 constexpr int kNwThreads = 1024;
 constexpr int kNwRounds = 2;      // chunks of 8 k-mer positions per lane (the second round is 7/8 populated)
 constexpr int kNwChunks = 1920;   // chunks of a level-1 tile: 15360 records = 60 KB staged, runs of ~15 per bin;
-constexpr int kNwTile = kNwChunks * 8;  // with the tables 77 KB of LDS: two workgroups per CU
+                                  // (x 8 records) with the tables 77 KB of LDS: two workgroups per CU
+// with a payload (one mask byte per record: the extension index) the same tile would take 94 KB = ONE workgroup per CU
+// (measured 8.4 ms against 3.8 ms without payload); 1536 chunks = 12 288 records x 5 bytes + tables = 78 KB
+template <bool HAS_VAL>
+struct NwCfg {
+    static constexpr int ROUNDS = HAS_VAL ? 1 : kNwRounds;       // with the mask extraction two rounds need 72 VGPRs:
+    static constexpr int CHUNKS = HAS_VAL ? 1024 : kNwChunks;    // one workgroup of 1024 per CU.  One round: 8192 records
+    static constexpr int TILE = CHUNKS * 8;
+};
 
 template <bool FAST, bool HAS_VAL>
 __device__ __forceinline__ void nw_extract(const ReadSrc &S, const PartLevel &L, uint32_t k_, uint32_t tid, uint32_t nch,
                                            uint64_t c0, uint32_t r0, uint32_t nr, const int32_t *s_rel,
                                            const int32_t *s_wrel, const uint32_t *s_len, const uint64_t *s_words,
-                                           uint32_t *lhist, uint32_t (&lo)[8 * kNwRounds], uint32_t (&vals)[8 * kNwRounds],
-                                           uint32_t (&binrank)[8 * kNwRounds]) {
+                                           uint32_t *lhist, uint32_t (&lo)[8 * NwCfg<HAS_VAL>::ROUNDS],
+                                           uint32_t (&binrank)[8 * NwCfg<HAS_VAL>::ROUNDS]) {
     constexpr int CH = 8;
 #pragma unroll
-    for (int r = 0; r < kNwRounds; ++r) {
+    for (int r = 0; r < NwCfg<HAS_VAL>::ROUNDS; ++r) {
         const uint32_t ci = (uint32_t)r * kNwThreads + tid;  // chunk of this lane inside the tile
         Key<1> kk[CH];
         uint32_t vv[CH], br[CH];
@@ -1872,8 +1880,10 @@ __device__ __forceinline__ void nw_extract(const ReadSrc &S, const PartLevel &L,
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             lo[r * CH + i] = (uint32_t)kk[i].w[0];
-            vals[r * CH + i] = vv[i];
-            binrank[r * CH + i] = br[i];
+            // payload (8 mask bits) | bin (10 bits) | rank (< 16384): one register per record instead of two -- with a
+            // separate payload array the kernel needed 80 VGPRs, which is one workgroup of 1024 per CU instead of two
+            binrank[r * CH + i] = br[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu
+                                                       : ((HAS_VAL ? vv[i] << 24 : 0u) | ((br[i] >> 16) << 14) | (br[i] & 0x3FFFu));
         }
     }
 }
@@ -1885,8 +1895,8 @@ __device__ __forceinline__ void nw_extract(const ReadSrc &S, const PartLevel &L,
 template <bool HAS_VAL>
 __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, PartLevel L, uint32_t *__restrict__ cursor,
                                                                  uint32_t *__restrict__ out, uint32_t *__restrict__ vout) {
-    constexpr int NT = kNwThreads, CH = 8, MAXB = kNwBins1, ITEMS = CH * kNwRounds;
-    constexpr int MW = kNwTile / 64;  // 64-bit mark words
+    constexpr int NT = kNwThreads, CH = 8, MAXB = kNwBins1, ITEMS = CH * NwCfg<HAS_VAL>::ROUNDS;
+    constexpr int MW = NwCfg<HAS_VAL>::TILE / 64;  // 64-bit mark words
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *lhist = reinterpret_cast<uint32_t *>(smem);
     uint32_t *lstart = lhist + MAXB;
@@ -1901,7 +1911,7 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
     uint32_t *s_len = reinterpret_cast<uint32_t *>(s_wrel + (kRdSlots + 2));
     uint64_t *s_words = reinterpret_cast<uint64_t *>(s_len + (kRdSlots + 2));
     uint32_t *stage = reinterpret_cast<uint32_t *>(U);
-    uint8_t *vstage = reinterpret_cast<uint8_t *>(stage + kNwTile);  // payloads of this path are 8 mask bits
+    uint8_t *vstage = reinterpret_cast<uint8_t *>(stage + NwCfg<HAS_VAL>::TILE);  // payloads of this path are 8 mask bits
 
     const uint32_t tid = threadIdx.x;
     const uint32_t k_ = (uint32_t)S.k;
@@ -1916,9 +1926,9 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
 #endif
 
     const uint32_t tile = blockIdx.x;
-    const uint64_t c0 = (uint64_t)tile * kNwChunks;
+    const uint64_t c0 = (uint64_t)tile * NwCfg<HAS_VAL>::CHUNKS;
     const uint64_t left = S.n_chunks - c0;
-    const uint32_t nch = left < (uint64_t)kNwChunks ? (uint32_t)left : (uint32_t)kNwChunks;
+    const uint32_t nch = left < (uint64_t)NwCfg<HAS_VAL>::CHUNKS ? (uint32_t)left : (uint32_t)NwCfg<HAS_VAL>::CHUNKS;
     const RdTile T = S.tiles[tile];
     const uint32_t r0 = T.r0, nr = T.nr;
     const uint64_t wbase = T.wbase;
@@ -1946,11 +1956,11 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
     }
 
     BBK_PH(5, 0, t_prev);  // read tables + words into LDS
-    uint32_t lo[ITEMS], vals[ITEMS], binrank[ITEMS];
+    uint32_t lo[ITEMS], binrank[ITEMS];
     // (two instantiations: the address space of the packed words -- LDS or global -- must be static, a pointer that may
     // be either compiles to flat loads)
-    if (fast) nw_extract<true, HAS_VAL>(S, L, k_, tid, nch, c0, r0, nr, s_rel, s_wrel, s_len, s_words, lhist, lo, vals, binrank);
-    else nw_extract<false, HAS_VAL>(S, L, k_, tid, nch, c0, r0, nr, s_rel, s_wrel, s_len, s_words, lhist, lo, vals, binrank);
+    if (fast) nw_extract<true, HAS_VAL>(S, L, k_, tid, nch, c0, r0, nr, s_rel, s_wrel, s_len, s_words, lhist, lo, binrank);
+    else nw_extract<false, HAS_VAL>(S, L, k_, tid, nch, c0, r0, nr, s_rel, s_wrel, s_len, s_words, lhist, lo, binrank);
     __syncthreads();  // histogram complete; the read tables may be overwritten by the stage
     BBK_PH(5, 1, t_prev);  // extraction + LDS ranking (two rounds)
 
@@ -1988,9 +1998,9 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         if (binrank[i] != 0xFFFFFFFFu) {
-            const uint32_t pos = lstart[binrank[i] >> 16] + (binrank[i] & 0xFFFFu);
+            const uint32_t pos = lstart[(binrank[i] >> 14) & 1023u] + (binrank[i] & 0x3FFFu);
             stage[pos] = lo[i];
-            if (HAS_VAL) vstage[pos] = (uint8_t)vals[i];
+            if (HAS_VAL) vstage[pos] = (uint8_t)(binrank[i] >> 24);
         }
     }
     goff[tid] = greserve - ex;
@@ -2052,29 +2062,35 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
 
 static size_t part_reads_narrow_smem(bool has_val) {
     const size_t tables = sizeof(uint32_t) * 3 * (kRdSlots + 2) + sizeof(uint64_t) * (kRdWords + 1 + 2);
-    const size_t stage = (size_t)kNwTile * (has_val ? 5 : 4);
-    const size_t fixed = sizeof(uint32_t) * (3 * kNwBins1 + 64) + (size_t)(kNwTile / 64) * (8 + 2) + (size_t)kNwBins1 * 2;
+    const size_t tile = has_val ? NwCfg<true>::TILE : NwCfg<false>::TILE;
+    const size_t stage = tile * (has_val ? 5 : 4);
+    const size_t fixed = sizeof(uint32_t) * (3 * kNwBins1 + 64) + (tile / 64) * (8 + 2) + (size_t)kNwBins1 * 2;
     return fixed + std::max(tables, stage);
 }
 
 // Level 2: one tile (<= 16384 records) of one segment -> the bucket slots of that segment.  Everything derives from lo.
 constexpr int kNw2Threads = 1024;
-constexpr int kNw2Items = 16;
-constexpr int kNw2Tile = kNw2Threads * kNw2Items;
+// records per lane: 12 without payload (60 VGPRs: two workgroups of 1024 per CU; with 16 the kernel needed 72 and ran
+// one: 3.2 -> 2.6 ms at BASELINE configs[1]), 8 with a payload (the mask array costs the registers of four records)
+template <bool HAS_VAL>
+struct Nw2Cfg {
+    static constexpr int ITEMS = HAS_VAL ? 8 : 12;
+    static constexpr int TILE = kNw2Threads * ITEMS;
+};
 
 template <bool HAS_VAL>
 __global__ __launch_bounds__(kNw2Threads) void k_part_narrow2(const uint32_t *__restrict__ in, const uint32_t *__restrict__ vin,
                                                              const uint4 *__restrict__ desc, PartLevel L,
                                                              uint32_t *__restrict__ cursor, uint32_t *__restrict__ out,
                                                              uint32_t *__restrict__ vout) {
-    constexpr int NT = kNw2Threads, ITEMS = kNw2Items, MAXB = kMaxBins;
+    constexpr int NT = kNw2Threads, ITEMS = Nw2Cfg<HAS_VAL>::ITEMS, MAXB = kMaxBins;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *lhist = reinterpret_cast<uint32_t *>(smem);
     uint32_t *lstart = lhist + MAXB;
     uint32_t *goff = lstart + MAXB;
     uint32_t *scan_tmp = goff + MAXB;
     uint32_t *stage = scan_tmp + 32;
-    uint32_t *vstage = stage + kNw2Tile;
+    uint32_t *vstage = stage + Nw2Cfg<HAS_VAL>::TILE;
     const uint32_t tid = threadIdx.x;
     const int hb = L.narrow_hb;
     const uint4 d = desc[blockIdx.x];  // first record, records, bins of the segment | segment << 16, flat index of bin 0
@@ -2160,7 +2176,7 @@ __global__ __launch_bounds__(kNw2Threads) void k_part_narrow2(const uint32_t *__
 }
 
 static size_t part_narrow2_smem(bool has_val) {
-    return sizeof(uint32_t) * (3 * kMaxBins + 32) + (size_t)kNw2Tile * 4 * (has_val ? 2 : 1);
+    return sizeof(uint32_t) * (3 * kMaxBins + 32) + (size_t)(has_val ? Nw2Cfg<true>::TILE : Nw2Cfg<false>::TILE) * 4 * (has_val ? 2 : 1);
 }
 
 // level-2 tile descriptors of the narrow path: like k_tile_desc, with the segment id beside the bin count
@@ -2610,7 +2626,8 @@ struct MsdRunner {
 
         // level-1 tiles cover the whole instance space; a range pass keeps its share of every tile.  Reads:
         // a tile is `threads` chunks, so the histogram (512 threads) and the scatter (1024) have their own tables
-        const uint32_t rd_tile = narrow ? (uint32_t)kNwChunks : (uint32_t)kRdThreads;  // chunks of a level-1 tile
+        const uint32_t rd_tile = narrow ? (uint32_t)(has_val ? NwCfg<true>::CHUNKS : NwCfg<false>::CHUNKS)
+                                        : (uint32_t)kRdThreads;  // chunks of a level-1 tile
         const uint32_t ntiles1 = from_reads ? (uint32_t)((n_chunks + rd_tile - 1) / rd_tile)
                                             : (uint32_t)((Ntot + kPartTileK - 1) / kPartTileK);
         const uint32_t ntiles1h = (uint32_t)((n_chunks + kRdHistThreads - 1) / kRdHistThreads);
@@ -2651,7 +2668,10 @@ struct MsdRunner {
         // instead of the two histogram passes.  The prefix is the key itself, so the spread is only as even as the
         // data: ANY record that misses its slot, any bucket the sort kernel turns down, any duplicate sends the call
         // back to the exact path (the slots cannot be patched up in key order the way the hash slots can).
-        const bool kslots = kslots_ok && slots_ok && !has_dst && !from_reads && !ranged && assume_distinct &&
+        // (only for EXPANDED input: both strands of a set spread evenly over the key space; a canonical set does not --
+        // its last base is A four times as often as T -- and 119 of 512 segments overflowed their slots in every
+        // extension-index build: 3.8 ms of a 30 ms build spent on an attempt that never holds)
+        const bool kslots = kslots_ok && slots_ok && !has_dst && !from_reads && !ranged && assume_distinct && expand_k != 0 &&
                             (dmode == MSD_KEYS || dmode == MSD_REF) && nb1 > 1 && N >= slots_min &&
                             getenv("BBK_NO_DIRECT") == nullptr && (double)N / fill * 1.1 + (double)N < 4.2e9;
         const bool slots = hslots || kslots;
@@ -2781,7 +2801,7 @@ struct MsdRunner {
         }
         tstart[0] = 0;
         sbin[0] = 0;
-        const uint32_t tile2 = narrow ? (uint32_t)kNw2Tile : kPartTileK;
+        const uint32_t tile2 = narrow ? (uint32_t)(has_val ? Nw2Cfg<true>::TILE : Nw2Cfg<false>::TILE) : kPartTileK;
         for (uint32_t b = 0; b < nb1; ++b) {
             tstart[b + 1] = tstart[b] + (h1[b] + tile2 - 1) / tile2;
             snb2[b] = (uint32_t)std::min<double>(kMaxBins, std::max(1.0, std::ceil((double)h1[b] / target)));
