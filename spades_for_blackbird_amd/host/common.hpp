@@ -2,6 +2,8 @@
 // (common/utils/logger: elapsed time prefix), C-ABI error handling, batched upload of reads.
 #pragma once
 
+#include <unistd.h>
+
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
@@ -72,6 +74,19 @@ struct Phases {
         fflush(stdout);
     }
 };
+
+// End of a tool whose outputs are written and closed: leave without tearing down the context and the HIP runtime
+// (unmapping tens of GB of device and pinned memory chunk by chunk cost 0.1-0.15 s of a 1 s run; the process image goes
+// away as a whole anyway).  BBK_FULL_TEARDOWN=1 (leak checks, sanitizer builds) takes the long way.
+[[noreturn]] inline void finish_process(bbk_ctx *ctx, int code) {
+    fflush(stdout);
+    fflush(stderr);
+    if (getenv("BBK_FULL_TEARDOWN")) {
+        bbk_ctx_destroy(ctx);
+        exit(code);
+    }
+    _exit(code);
+}
 
 inline int default_threads() {
     int t = omp_get_max_threads();

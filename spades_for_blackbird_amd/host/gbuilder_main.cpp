@@ -149,7 +149,6 @@ int main(int argc, char **argv) {
     bbk_extindex_free(ext);
     ph.total = now_s() - t_start;
     ph.report("spades-gbuilder");
-    bbk_ctx_destroy(ctx);
     info("SPAdes standalone graph builder finished");
-    return 0;
+    finish_process(ctx, 0);
 }

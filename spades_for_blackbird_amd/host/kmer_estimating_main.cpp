@@ -63,6 +63,5 @@ int main(int argc, char **argv) {
     check(bbk_count_finish(counter, &set), "bbk_count_finish");
     info("Kmer number estimation: %llu", (unsigned long long)bbk_kmerset_size(set));  // :99, exact here
     bbk_kmerset_free(set);
-    bbk_ctx_destroy(ctx);
-    return 0;
+    finish_process(ctx, 0);
 }

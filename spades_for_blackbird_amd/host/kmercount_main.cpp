@@ -102,6 +102,5 @@ int main(int argc, char **argv) {
     bbk_kmerset_free(set);
     ph.total = now_s() - t_start;
     ph.report("spades-kmercount");
-    bbk_ctx_destroy(ctx);
-    return 0;
+    finish_process(ctx, 0);
 }

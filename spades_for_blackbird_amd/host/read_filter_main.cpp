@@ -249,6 +249,5 @@ int main(int argc, char **argv) {
     info("Saving filtered dataset description to %s", fname.c_str());
     if (!save_dataset_yaml(fname, outlibs)) fatal("Cannot write %s", fname.c_str());
     bbk_kmerset_free(counts);
-    bbk_ctx_destroy(ctx);
-    return 0;
+    finish_process(ctx, 0);
 }
