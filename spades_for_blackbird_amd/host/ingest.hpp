@@ -24,6 +24,9 @@
 //   * bases are upper-cased by kseq; the packing accepts both cases (common/sequence/nucl.hpp:45-62,120-130).
 #pragma once
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -68,8 +71,57 @@ inline const unsigned char *nucl_table() {
     return t.v;
 }
 
+#if defined(__x86_64__)
+// AVX2 forms of the two per-base loops (chosen at run time; the scalar code below is the reference and the fallback):
+// a line of a read file is almost always nothing but ACGT, so "is the whole string valid" decides LongestValid in one
+// pass of 32 bytes per step, and 32 bases are packed into one 64-bit word with two multiply-adds and a byte shuffle.
+__attribute__((target("avx2"))) inline bool all_valid_avx2(const char *s, size_t n) {
+    const __m256i up = _mm256_set1_epi8((char)0xDF);
+    const __m256i a = _mm256_set1_epi8('A'), c = _mm256_set1_epi8('C'), g = _mm256_set1_epi8('G'), t = _mm256_set1_epi8('T');
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m256i v = _mm256_and_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i)), up);
+        const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, a), _mm256_cmpeq_epi8(v, c)),
+                                           _mm256_or_si256(_mm256_cmpeq_epi8(v, g), _mm256_cmpeq_epi8(v, t)));
+        if ((uint32_t)_mm256_movemask_epi8(ok) != 0xFFFFFFFFu) return false;
+    }
+    if (i < n) {  // the last (n mod 32) bytes: one more block ending at the end of the string (n >= 32)
+        const __m256i v = _mm256_and_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + n - 32)), up);
+        const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, a), _mm256_cmpeq_epi8(v, c)),
+                                           _mm256_or_si256(_mm256_cmpeq_epi8(v, g), _mm256_cmpeq_epi8(v, t)));
+        if ((uint32_t)_mm256_movemask_epi8(ok) != 0xFFFFFFFFu) return false;
+    }
+    return true;
+}
+// 32 ASCII bases (all ACGTacgt) -> 64 bits, base 0 in the low bits
+__attribute__((target("avx2"))) inline uint64_t pack32_avx2(const char *s) {
+    const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s));
+    // code = ((c >> 1) ^ (c >> 2)) & 3 per byte (the 16-bit shifts only leak into bits that the mask drops)
+    const __m256i code = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), _mm256_set1_epi8(3));
+    const __m256i p4 = _mm256_maddubs_epi16(code, _mm256_set1_epi16(0x0401));  // words: b0 + 4 b1
+    const __m256i p8 = _mm256_madd_epi16(p4, _mm256_set1_epi32(0x00100001));   // dwords: w0 + 16 w1 = 4 bases in 8 bits
+    const __m256i sh = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                        0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    const __m256i q = _mm256_shuffle_epi8(p8, sh);  // low dword of each 128-bit lane = 16 bases
+    return (uint64_t)(uint32_t)_mm256_extract_epi32(q, 0) | ((uint64_t)(uint32_t)_mm256_extract_epi32(q, 4) << 32);
+}
+inline bool have_avx2() {
+    static const bool v = __builtin_cpu_supports("avx2") && getenv("BBK_NO_AVX2") == nullptr;
+    return v;
+}
+#else
+inline bool have_avx2() { return false; }
+inline bool all_valid_avx2(const char *, size_t) { return false; }
+inline uint64_t pack32_avx2(const char *) { return 0; }
+#endif
+
 // longest maximal run of ACGTacgt, first wins on ties (longest_valid_wrapper.hpp:15-41)
 inline void longest_valid(const char *s, size_t n, size_t *from, size_t *to) {
+    if (n >= 32 && have_avx2() && all_valid_avx2(s, n)) {
+        *from = 0;
+        *to = n;
+        return;
+    }
     const unsigned char *ok = nucl_table();
     size_t best = 0, best_pos = 0, i = 0;
     while (i < n) {
@@ -97,20 +149,29 @@ inline uint64_t pack8(const char *s) {
 }
 
 inline void pack_run(const char *s, size_t n, std::vector<uint64_t> &words) {
-    size_t i = 0;
-    while (i + 32 <= n) {
-        words.push_back(pack8(s + i) | (pack8(s + i + 8) << 16) | (pack8(s + i + 16) << 32) | (pack8(s + i + 24) << 48));
-        i += 32;
+    const size_t nw = (n + 31) / 32, o = words.size();
+    if (nw == 0) return;
+    words.resize(o + nw);  // one growth check per run instead of one per word
+    uint64_t *w = words.data() + o;
+    size_t i = 0, j = 0;
+    if (have_avx2()) {
+        for (; i + 32 <= n; i += 32) w[j++] = pack32_avx2(s + i);
+        if (i < n && n >= 32) {  // the last (n mod 32) bases: the 32 bases ending at the end of the run, shifted down
+            w[j] = pack32_avx2(s + n - 32) >> (2 * (32 - (n - i)));
+            return;
+        }
     }
+    for (; i + 32 <= n; i += 32)
+        w[j++] = pack8(s + i) | (pack8(s + i + 8) << 16) | (pack8(s + i + 16) << 32) | (pack8(s + i + 24) << 48);
     if (i < n) {
-        uint64_t w = 0;
+        uint64_t x = 0;
         int sh = 0;
-        for (; i + 8 <= n; i += 8, sh += 16) w |= pack8(s + i) << sh;
+        for (; i + 8 <= n; i += 8, sh += 16) x |= pack8(s + i) << sh;
         for (; i < n; ++i, sh += 2) {
             const unsigned c = (unsigned char)s[i];
-            w |= (uint64_t)(((c >> 1) ^ (c >> 2)) & 3u) << sh;
+            x |= (uint64_t)(((c >> 1) ^ (c >> 2)) & 3u) << sh;
         }
-        words.push_back(w);
+        w[j] = x;
     }
 }
 
