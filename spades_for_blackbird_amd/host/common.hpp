@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -99,11 +100,15 @@ inline int default_threads() {
 // its parsing master thread with the consuming workers the same way, common/io/reads/read_processor.hpp:76-135).
 // block_bytes bounds the host memory: two blocks of text-equivalent packed reads are alive at any time (the -b
 // contract of the reference: bounded buffers, kmer_splitter.hpp:73-109).
+// `init` (optional) runs on this thread right after the parser thread has been started and before the first upload:
+// the tools create the HIP context (0.1-0.2 s) and their accumulators there, under the parse of the first block; `ctx` is
+// read after it.
 template <class Push>
-inline uint64_t stream_reads(bbk_ctx *ctx, const std::vector<std::string> &files, size_t block_bytes, int threads,
-                             Phases &ph, Push push) {
+inline uint64_t stream_reads(bbk_ctx *&ctx, const std::vector<std::string> &files, size_t block_bytes, int threads,
+                             Phases &ph, Push push, const std::function<void()> &init = nullptr) {
     // a single SPAdes binary read cache (<prefix>.seq) is taken as is
     if (files.size() == 1 && ends_with(files[0], ".seq")) {
+        if (init) init();
         info("Processing %s (binary read cache)", files[0].c_str());
         bbk_reads *r = nullptr;
         check(bbk_reads_from_spades_binary(ctx, files[0].c_str(), &r), "bbk_reads_from_spades_binary");
@@ -140,6 +145,7 @@ inline uint64_t stream_reads(bbk_ctx *ctx, const std::vector<std::string> &files
             if (!more) return;
         }
     });
+    if (init) init();
     uint64_t total = 0;
     std::string fail;
     for (int i = 0;; i ^= 1) {

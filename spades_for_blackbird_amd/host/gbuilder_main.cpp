@@ -91,21 +91,24 @@ int main(int argc, char **argv) {
     Phases ph;
     const double t_start = now_s();
     bbk_ctx *ctx = nullptr;
-    check(bbk_ctx_create((int)device, &ctx), "bbk_ctx_create");
-    ph.ctx = now_s() - t_start;
-
     // Step 1: build extension index (:169-172), block by block; with -c the canonical (k+1)-mer multiplicities
-    // (CoverageHashMapBuilder, :200-211) are counted from the same blocks
+    // (CoverageHashMapBuilder, :200-211) are counted from the same blocks.  The context (HIP initialisation:
+    // 0.1-0.2 s) and the two accumulators are created while the first block is being parsed.
     bbk_extbuilder *xb = nullptr;
-    check(bbk_extindex_begin(ctx, k, &xb), "bbk_extindex_begin");
     bbk_counter *covc = nullptr;
     const bool want_cov = coverage && mode != UNITIGS;
-    if (want_cov) check(bbk_count_begin(ctx, k + 1, BBK_CANONICAL | BBK_WITH_COUNTS, &covc), "bbk_count_begin");
+    auto init = [&] {
+        const double t0c = now_s();
+        check(bbk_ctx_create((int)device, &ctx), "bbk_ctx_create");
+        ph.ctx = now_s() - t0c;
+        check(bbk_extindex_begin(ctx, k, &xb), "bbk_extindex_begin");
+        if (want_cov) check(bbk_count_begin(ctx, k + 1, BBK_CANONICAL | BBK_WITH_COUNTS, &covc), "bbk_count_begin");
+    };
     const uint64_t n_reads =
         stream_reads(ctx, files, (size_t)bufsize, threads ? (int)threads : default_threads(), ph, [&](bbk_reads *r) {
             check(bbk_extindex_push_reads(xb, r), "bbk_extindex_push_reads");
             if (covc) check(bbk_count_push_reads(covc, r), "bbk_count_push_reads");
-        });
+        }, init);
     info("Used %llu reads", (unsigned long long)n_reads);
     double t0 = now_s();
     bbk_extindex *ext = nullptr;
