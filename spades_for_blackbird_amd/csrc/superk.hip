@@ -518,7 +518,10 @@ __device__ __forceinline__ void sk_roll(Key<W> &F, Key<W> &RC, uint32_t k, uint3
     if (vb < 64u) RC.w[W - 1] &= (1ull << vb) - 1ull;
 }
 
-constexpr int kSkdSR = 4;  // k-mers of a work item (consecutive k-mers of one record, rolled)
+#ifndef BBK_SKD_SR
+#define BBK_SKD_SR 4
+#endif
+constexpr int kSkdSR = BBK_SKD_SR;  // k-mers of a work item (consecutive k-mers of one record, rolled)
 
 // F <= RC in base order (base 0 most significant, rtseq.hpp:732-741): decided by the first base in which they differ
 template <int W>
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
     uint32_t *table = newidx + STG;                                           // [TS]
     uint32_t *tvals = table + TS;                                             // [TS] (OP)
     uint32_t *tmp = tvals + (OP ? TS : 0);                                    // [64]
-    uint16_t *work = reinterpret_cast<uint16_t *>(tmp + 64);                  // [STG * ipr]: record << 4 | item of the record
+    uint16_t *work = reinterpret_cast<uint16_t *>(tmp + 64);                  // [STG * ipr]: record << 5 | item of the record
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = bucket_ids ? bucket_ids[blockIdx.x] : blockIdx.x;
     const unsigned long long r_begin = boff[b], r_end = boff[b + 1];
@@ -642,14 +645,14 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
             uint32_t before = 0;
             for (uint32_t j = 0; j < wave; ++j) before += tmp[j];
             const uint32_t first = before + incl - items;
-            for (uint32_t q = 0; q < items; ++q) work[first + q] = (uint16_t)((tid << 4) | q);
+            for (uint32_t q = 0; q < items; ++q) work[first + q] = (uint16_t)((tid << 5) | q);
             if (tid == NT - 1) ioff[STG] = before + incl;
         }
         __syncthreads();
         const uint32_t total = ioff[STG];
         for (uint32_t it = tid; it < total; it += NT) {
             const uint32_t wk = work[it];
-            const uint32_t r = wk >> 4, j0 = (wk & 15u) * SR;
+            const uint32_t r = wk >> 5, j0 = (wk & 31u) * SR;
             const uint64_t *rp = stg + r * RW;
             const uint32_t hdr = (uint32_t)(rp[RW - 1] >> kSkHdrShift);
             const uint32_t n = (hdr & 63u) + 1u;
