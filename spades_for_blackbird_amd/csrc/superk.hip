@@ -934,12 +934,14 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     // Buckets are planned by INSTANCES: the dedup table holds distinct keys, at most the instances of its bucket
     const double per_seg = 1.0 + (double)(C - 1) * 2.0 / (double)(w + 1);
     const double est_total = (double)n_segs * per_seg * 1.05 + 65536.0;
-    // The table holds DISTINCT keys.  Planned for the multiplicity of the previous batch of this context (x 0.8; none
+    // The table holds DISTINCT keys.  Planned for the multiplicity of the previous batch of this context (x 0.5; none
     // yet: 1, every instance its own key): a bucket costs ~15 us of dependent latencies whatever it holds, so buckets
     // a quarter full would spend most of the kernel's time on them.  A batch that turns out less repetitive sends
     // its fuller buckets to the second-chance table (4x the slots) and, past 65536 of those, back to the k-mer path.
     const char *ef = getenv("BBK_SUPERK_FILL");  // tests: overfull buckets exercise the second-chance table
-    const double dup_plan = std::min(4.0, std::max(1.0, 0.8 * ctx->superk_dup));
+    // (x 0.5: measured at k = 55, multiplicity 3.7 -- planned instances per slot 0.55: 12.3 ms, 1.0: 10.1, 1.3: 10.4,
+    // 1.63: 11.5, 2.0: 14.5, 2.4: 20.8; the table wants a load of ~0.3)
+    const double dup_plan = std::min(4.0, std::max(1.0, 0.5 * ctx->superk_dup));
     const double fill = ef ? atof(ef) : 0.55 * dup_plan;
     const double nb_total = std::max(1.0, std::ceil((double)N / (fill * SkdA::TS)));
     const char *eb = getenv("BBK_SUPERK_BUCKETS");
