@@ -104,8 +104,12 @@ def _configs2_full_size():
     assert desc == 0 and eq == 0, "extension index keys are not strictly ascending"
     assert int(xm.min().item()) >= 1
     pop = torch.tensor([bin(i).count("1") for i in range(16)], dtype=torch.int64, device="cuda")
-    outs = int(pop[(xm & 15).long()].sum().item())
-    ins = int(pop[(xm >> 4).long()].sum().item())
+    outs = ins = 0
+    for a0 in range(0, nx, 1 << 28):  # in pieces: the index tensors of the whole array would take 2 x 20 GB next to the engine's arena
+        m = xm[a0:a0 + (1 << 28)]
+        outs += int(pop[(m & 15).long()].sum().item())
+        ins += int(pop[(m >> 4).long()].sum().item())
+        del m
     # every distinct canonical (k+1)-mer sets exactly two bits (AddOutgoing on its prefix k-mer, AddIncoming on its suffix
     # k-mer, kmer_extension_index_builder.hpp:44-59; a palindromic 56-mer would set one, probability 4^-28 each)
     xk_keep = xk
