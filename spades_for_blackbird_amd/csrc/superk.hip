@@ -946,8 +946,20 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     const double nb_total = std::max(1.0, std::ceil((double)N / (fill * SkdA::TS)));
     const char *eb = getenv("BBK_SUPERK_BUCKETS");
     const double per_pass_max = eb ? (double)strtoull(eb, nullptr, 10) : (double)(1u << kSkMaxP1Bits) * kSkMaxP2 * 0.9;
-    const uint32_t np = (uint32_t)std::max(1.0, std::ceil(nb_total / per_pass_max));
-    const double nbp = std::ceil(nb_total / np);
+    uint32_t np = (uint32_t)std::max(1.0, std::ceil(nb_total / per_pass_max));
+    // one pass fewer when somewhat fuller buckets allow it: a pass re-reads the reads and repeats the minimizer work (38 ms
+    // per 100 M reads), fuller tables cost less than that up to ~1.8x the planned load (configs[2]: 2 passes at 1.03
+    // instances per slot = 390 ms of stage A, 1 pass at 1.24 = 330 ms)
+    double nb_plan = nb_total;
+    if (np > 1 && !ef) {
+        const double fill_max = 0.55 * std::min(4.0, std::max(1.0, 0.9 * ctx->superk_dup));
+        const double need = (double)N / (SkdA::TS * per_pass_max * (np - 1));
+        if (need <= fill_max) {
+            --np;
+            nb_plan = std::ceil((double)N / (need * SkdA::TS));
+        }
+    }
+    const double nbp = std::ceil(nb_plan / np);
     const double want1 = std::max(64.0, nbp / 768.0);
     uint32_t b1bits = 0;
     while (b1bits < kSkMaxP1Bits && (double)(1u << b1bits) < want1 && (double)(1u << b1bits) < nbp) ++b1bits;
@@ -976,7 +988,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     if (verbose)
         fprintf(stderr,
                 "[bbk] superk: k=%u m=%u w=%u C=%u segs=%llu est_records=%.0f passes=%u P1=%u P2=%u slot1=%u lds1=%zu fill=%.2f\n",
-                k, m, w, C, (unsigned long long)n_segs, est_total, np, P1, P2, P.slot1, sm1, fill);
+                k, m, w, C, (unsigned long long)n_segs, est_total, np, P1, P2, P.slot1, sm1, (double)N / (nb_plan * SkdA::TS));
 
     DevBuf tiles((size_t)(ntiles1 + 1) * sizeof(SkTile));
     hipLaunchKernelGGL(k_sk_tiles, dim3((unsigned)((ntiles1 + 255) / 256)), dim3(256), 0, ctx->stream, coff.as<uint64_t>(),
