@@ -910,7 +910,9 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     // without natural runs (<= k-m+1 k-mers) exceeding the record, within [15, 31]
     const uint32_t nbase_max = (64u * RW - kSkHdrBits) / 2u;
     const uint32_t n_cap = std::min<uint32_t>(64u, nbase_max - k + 1u);
-    const uint32_t m = (uint32_t)std::min<int>(31, std::max<int>(15, (int)k - (int)n_cap + 1));
+    const char *em = getenv("BBK_SUPERK_M");  // experiments: minimizer length (11..31, at least k - 63)
+    const uint32_t m = em ? (uint32_t)std::min<int>(31, std::max<int>(std::max(11, (int)k - 63), atoi(em)))
+                          : (uint32_t)std::min<int>(31, std::max<int>(15, (int)k - (int)n_cap + 1));
     const uint32_t w = k - m + 1u;
     const uint32_t C = std::min(w, n_cap);
 
