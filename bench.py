@@ -35,9 +35,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md), the figure fractions are quoted against
-FAMILIES = ["extract", "hist", "scan", "scatter", "unique", "reduce", "expand", "part_hist0", "part_hist1_reads",
-            "part_hist1_keys", "part_scatter1_reads", "part_scatter1_keys", "part_hist2", "part_scatter2", "lds_dedup",
-            "lds_sort", "compact", "sk_part1", "sk_hist2", "sk_part2", "sk_dedup", "sk_dedup2", "part_scatter0_keys"]
+# Timer names are kernel symbols (one name per kernel template, the way rocprofv3 lists them; tools/pmc_summary.py holds
+# the symbol -> name table), so that "the dominant kernel" is a kernel and not a group of them.
+FAMILIES = ["extract", "hist", "scan", "scatter", "unique", "reduce", "expand", "compact",
+            "k_part_reads_narrow", "k_part_narrow2", "k_bucket_hash32",                      # stage A, 4-byte records (k 17..21)
+            "k_part_reads", "k_part_reads_hist",                                              # stage A from reads, full keys
+            "k_part_hist0", "k_part_l0", "k_part_hist1", "k_part_l1", "k_part_hist2", "k_part_l2",  # key arrays (stage B, merges)
+            "k_bucket_hash", "k_bucket_hashidx", "k_bucket_dist", "k_bucket",                 # buckets finished in LDS
+            "k_sk_part1", "k_sk_part2_hist", "k_sk_part2", "k_sk_dedup", "k_sk_dedup_B", "k_sk_expand"]  # super-k-mer records
 # HBM traffic from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate runs of this very
 # command and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py).  A profiler cannot run
 # inside the timed process, so the committed summary is attached when the workload is the one it was
@@ -287,18 +292,33 @@ def metagenome(ctx, args, B, fence):
     return out
 
 
-def roofline_of(prof, steps, traffic_lookup=None):
-    dom = max(prof, key=lambda f: prof[f]["ms"]) if prof else None
-    if not dom:
+def roofline_of(prof, steps, traffic_lookup=None, step_ms=None):
+    """`roofline` object of one timed loop.  Keyed by KERNEL (the timer names are kernel symbols): the dominant kernel is
+    the one with the largest summed duration over the timed steps; `kernels` lists every kernel of the step the same
+    way (so the object still holds the figures when two kernels are close and the dominant one changes between
+    runs), `step` is the whole step: sum of the kernels' algorithmic bytes over the wall time of a step."""
+    if not prof:
         return None
-    p = prof[dom]
-    ach = p["bytes"] / (p["ms"] * 1e-3) / 1e9
-    traffic, traffic_src = (traffic_lookup(dom) if traffic_lookup else (None, None))
-    out = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-           "launches": p["launches"], "avg_launch_ms": p["ms"] / p["launches"],
-           "algorithmic_bytes_per_launch": p["bytes"] / p["launches"]}
-    if dom.startswith("sk_dedup"):
+
+    def entry(name):
+        p = prof[name]
+        ach = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
+        traffic, traffic_src = (traffic_lookup(name) if traffic_lookup else (None, None))
+        return {"kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_src, "launches": p["launches"],
+                "avg_launch_ms": p["ms"] / p["launches"], "ms_per_step": p["ms"] / steps,
+                "algorithmic_bytes_per_launch": p["bytes"] / p["launches"]}
+
+    order = sorted(prof, key=lambda f: -prof[f]["ms"])
+    out = {"bound": "hbm"}
+    out.update(entry(order[0]))
+    out["kernels"] = [entry(f) for f in order if prof[f]["bytes"] > 0]
+    tot_bytes = sum(v["bytes"] for v in prof.values()) / steps
+    if step_ms:
+        out["step"] = {"algorithmic_bytes": tot_bytes, "ms": step_ms, "achieved": tot_bytes / (step_ms * 1e-3) / 1e9,
+                       "frac": tot_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "kernel_ms": sum(v["ms"] for v in prof.values()) / steps}
+    if order[0].startswith("k_sk_dedup"):
         # the in-LDS table walk over super-k-mer records: vector-instruction bound (DESIGN.md 4.1b: SQ counters), it
         # reads 1/13 of the bytes the k-mer path's dedup read -- the HBM fraction says how little it moves, not how busy it is
         out["note"] = "VALU/LDS-bound kernel (in-LDS dedup of packed super-k-mer records); quoted against HBM only because " \
@@ -430,7 +450,7 @@ def main():
                 if fam:
                     return fam["hbm_bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 --pmc)"
             return None, None
-        roof = roofline_of(prof, args.steps, pmc)
+        roof = roofline_of(prof, args.steps, pmc, dt_max / args.steps * 1e3)
         inst_per_gpu = 2 * args.reads * (L - k + 1)
         if args.ext_index:
             wl = ("BASELINE.json configs[2]: synthetic %d x %d bp uniform reads, k=%d, k-mer count (both strands, "
@@ -474,7 +494,7 @@ def main():
                            "steps": 2, "warmup": 1, "ms_per_step": dt55 / 2 * 1e3, "distinct_kmers": n55,
                            "value": n55 / (dt55 / 2), "unit": "distinct k-mers/s", "dtype": "u128",
                            "kernel_ms_per_step": {f: v["ms"] / 2 for f, v in prof55.items()},
-                           "roofline": roofline_of(prof55, 2)}
+                           "roofline": roofline_of(prof55, 2, None, dt55 / 2 * 1e3)}
         if world == 1 and not args.no_meta and not big:
             line["metagenome"] = metagenome(ctx, args, B, fence)
         if world == 1 and not args.no_gfa and not big:

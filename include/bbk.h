@@ -247,6 +247,11 @@ uint64_t bbk_unitigs_loops(const bbk_unitigs *u);
 uint64_t bbk_unitigs_total_bases(const bbk_unitigs *u);
 uint64_t bbk_unitigs_vertices(const bbk_unitigs *u);
 uint64_t bbk_unitigs_links(const bbk_unitigs *u);
+/* The condensed edges as a read set in HBM (packed on the device, nothing crosses PCIe): what the main pipeline does
+ * when it feeds the contigs of the previous K into the construction of the next
+ * (common/stages/construction.cpp:117-119,228-236: contigs_streams merged into the read streams), and what the
+ * full-size tests use to recount the (k+1)-mers of the graph. */
+int bbk_unitigs_to_reads(bbk_ctx *ctx, const bbk_unitigs *u, bbk_reads **out);
 /* h_bases: total_bases ASCII bytes (no separators); h_offsets: count+1 entries. */
 int bbk_unitigs_export(bbk_ctx *ctx, const bbk_unitigs *u, char *h_bases, uint64_t *h_offsets);
 /* links: 4 x u32 per link (from_unitig, from_orient(1='+'), to_unitig, to_orient) */

@@ -60,8 +60,9 @@ int guarded(F &&f) {
 
 void *pool_alloc(size_t bytes, size_t *granted, int *device);  // on the current device
 void pool_free(void *p, size_t bytes, int device);
-void pool_trim(int device);  // hipFree what this (device, host thread) has cached
+void pool_trim(int device);  // gives the free memory this (device, host thread) holds back to the driver
 void pool_report();          // allocator statistics to stderr
+size_t pool_mapped_bytes(int device);  // device memory the arenas of all host threads hold mapped on `device`
 
 // Owning device buffer.
 struct DevBuf {
@@ -272,6 +273,7 @@ struct bbk_extindex {
     uint64_t instances = 0;
     bbk::DevBuf keys;   // n * W u64 ascending (canonical k-mers)
     bbk::DevBuf masks;  // n u8
-    bbk::DevBuf prefix; // lookup accelerator: (1<<prefix_bits)+1 u32
+    bbk::DevBuf prefix; // lookup accelerator: (1<<prefix_bits)+1 entries, u32 (u64 when prefix_wide: 2^32-2 k-mers or more)
     unsigned prefix_bits = 0;
+    bool prefix_wide = false;
 };

@@ -27,32 +27,49 @@ __global__ void k_u32_to_u8(const uint32_t *__restrict__ in, uint64_t n, uint8_t
     if (i < n) out[i] = (uint8_t)in[i];
 }
 
-// pref[t] = first index whose top `bits` bits of word 0 are >= t  (t in [0, 2^bits])
-__global__ void k_prefix_table(const uint64_t *__restrict__ keys, int W, uint64_t n, int shift, uint32_t nbins,
-                               uint32_t *__restrict__ pref) {
+// pref[t] = first index whose top `bits` bits of word 0 are >= t  (t in [0, 2^bits]).  IDX = uint32_t below 2^32 - 2
+// records, uint64_t above (KMerIndex::seq_idx is a size_t, utils/kmer_mph/kmer_index.hpp:85-90)
+template <class IDX>
+__global__ void k_prefix_table(const uint64_t *__restrict__ keys, int W, uint64_t n, int shift, uint64_t nbins,
+                               IDX *__restrict__ pref) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t t = (uint32_t)(keys[i * W] >> shift);
+    const uint64_t t = keys[i * W] >> shift;
     const int64_t tp = (i == 0) ? -1 : (int64_t)(keys[(i - 1) * W] >> shift);
-    for (int64_t u = tp + 1; u <= (int64_t)t; ++u) pref[u] = (uint32_t)i;
+    for (int64_t u = tp + 1; u <= (int64_t)t; ++u) pref[u] = (IDX)i;
     if (i == n - 1)
-        for (uint32_t u = t + 1; u <= nbins; ++u) pref[u] = (uint32_t)n;
+        for (uint64_t u = t + 1; u <= nbins; ++u) pref[u] = (IDX)n;
+}
+
+// 64-bit table entries are chosen by size; BBK_WIDE_INDEX=1 forces them (tests run the wide graph stage on small inputs)
+bool index_is_wide(uint64_t n) {
+    return n >= (1ull << 32) - 2 || getenv("BBK_WIDE_INDEX") != nullptr;  // read per call: tests switch it inside a process
 }
 
 // Prefix table over an ascending key array: ~8 keys per bin; word 0 holds min(2k, 64) populated bits.
-// Returns the number of prefix bits; lookups shift word 0 right by (w0bits - bits).
-unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsigned k, uint64_t n, DevBuf &prefix) {
+// Returns the number of prefix bits; lookups shift word 0 right by (w0bits - bits).  *wide: the entries are u64.
+unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsigned k, uint64_t n, DevBuf &prefix,
+                            bool *wide) {
     const int w0bits = (W == 1) ? (int)(2 * k) : 64;
+    const int max_bits = n > (1ull << 27) ? 30 : 24;
     int bits = 4;
-    while (bits < 24 && (1ull << (bits + 3)) < n) ++bits;
+    while (bits < max_bits && (1ull << (bits + 3)) < n) ++bits;
     bits = std::min(bits, w0bits);
-    const uint32_t nbins = 1u << bits;
-    prefix.alloc(((size_t)nbins + 1) * sizeof(uint32_t));
+    const uint64_t nbins = 1ull << bits;
+    *wide = index_is_wide(n);
+    const size_t esz = *wide ? sizeof(uint64_t) : sizeof(uint32_t);
+    prefix.alloc(((size_t)nbins + 1) * esz);
     if (n == 0) {
-        BBK_HIP(hipMemsetAsync(prefix.p, 0, ((size_t)nbins + 1) * sizeof(uint32_t), ctx->stream));
+        BBK_HIP(hipMemsetAsync(prefix.p, 0, ((size_t)nbins + 1) * esz, ctx->stream));
     } else {
-        hipLaunchKernelGGL(k_prefix_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, keys, (int)W, n,
-                           w0bits - bits, nbins, prefix.as<uint32_t>());
+        const uint64_t nblk = (n + 255) / 256;
+        BBK_REQUIRE(nblk < (1ull << 31), BBK_ERR_ARG, "index of %llu k-mers exceeds the launch grid", (unsigned long long)n);
+        if (*wide)
+            hipLaunchKernelGGL(k_prefix_table<uint64_t>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, keys, (int)W, n,
+                               w0bits - bits, nbins, prefix.as<uint64_t>());
+        else
+            hipLaunchKernelGGL(k_prefix_table<uint32_t>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, keys, (int)W, n,
+                               w0bits - bits, nbins, prefix.as<uint32_t>());
         check_launch("k_prefix_table");
     }
     BBK_HIP(hipStreamSynchronize(ctx->stream));
@@ -60,14 +77,7 @@ unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsi
 }
 
 void build_prefix_table(bbk_ctx *ctx, bbk_extindex *x) {
-    // table entries are 32-bit record indices: an index of 2^32 or more k-mers (BASELINE configs[3] gathered on one
-    // device) carries no lookup table and the graph stage refuses it (unitigs.hip); keys and masks are complete
-    if (x->n >= (1ull << 32)) {
-        x->prefix.release();
-        x->prefix_bits = 0;
-        return;
-    }
-    x->prefix_bits = build_prefix_index(ctx, x->keys.as<uint64_t>(), x->W, x->k, x->n, x->prefix);
+    x->prefix_bits = build_prefix_index(ctx, x->keys.as<uint64_t>(), x->W, x->k, x->n, x->prefix, &x->prefix_wide);
 }
 
 // the accumulated (canonical k-mer, OR of mask bits) records -> the index: ascending keys, one InOutMask byte each

@@ -235,4 +235,37 @@ __host__ __device__ inline uint32_t rev8(uint32_t m) {
     return m;
 }
 
+// The sorted table of distinct k-mers IS the index (it replaces the BooPHF of utils/kmer_mph/kmer_index.hpp:85-90):
+// a prefix table over the top bits of word 0 bounds a short binary search.  Record indices are 64-bit like the
+// reference's size_t; the prefix table holds u32 entries below 2^32 - 2 records and u64 entries above (`wide`,
+// uniform over a launch).
+constexpr uint64_t kNotFound = ~0ull;
+struct PrefixTable {
+    const void *pref;
+    int pshift;
+    int wide;
+};
+template <int W>
+__device__ inline uint64_t table_find(const Key<W> *__restrict__ keys, const PrefixTable &P, const Key<W> &q) {
+    const uint64_t t = q.w[0] >> P.pshift;
+    uint64_t lo, hi;
+    if (P.wide) {
+        const uint64_t *p = reinterpret_cast<const uint64_t *>(P.pref);
+        lo = p[t];
+        hi = p[t + 1];
+    } else {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(P.pref);
+        lo = p[t];
+        hi = p[t + 1];
+    }
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        const Key<W> km = key_load<W>(&keys[mid]);
+        if (key_eq<W>(km, q)) return mid;
+        if (key_less_words<W>(km, q)) lo = mid + 1;
+        else hi = mid;
+    }
+    return kNotFound;
+}
+
 }  // namespace bbk

@@ -2422,7 +2422,7 @@ struct MsdRunner {
         auto fn = dist ? k_bucket_dist<W, NT, IT, OP> : k_bucket<W, NT, IT, OP>;
         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)sm));
-        KernelTimer t(ctx, "lds_sort", bytes);
+        KernelTimer t(ctx, dist ? "k_bucket_dist" : "k_bucket", bytes);
         hipLaunchKernelGGL(fn, dim3(nblocks), dim3(NT), sm, ctx->stream, buf, vals, A);
         check_launch("k_bucket");
     }
@@ -2435,7 +2435,7 @@ struct MsdRunner {
             auto fn = k_bucket_hash<OP>;
             BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)sm));
-            KernelTimer t(ctx, "lds_dedup", bytes);
+            KernelTimer t(ctx, "k_bucket_hash", bytes);
             hipLaunchKernelGGL(fn, dim3(nblocks), dim3(kHashThreads), sm, ctx->stream, buf, vals, A);
             check_launch("k_bucket_hash");
         }
@@ -2463,7 +2463,7 @@ struct MsdRunner {
             auto fn = k_bucket_hashidx<W, OP>;
             BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)sm));
-            KernelTimer t(ctx, "lds_dedup", bytes);
+            KernelTimer t(ctx, "k_bucket_hashidx", bytes);
             hipLaunchKernelGGL(fn, dim3(nblocks), dim3(kHashIdxThreads), sm, ctx->stream, buf, vals, A);
             check_launch("k_bucket_hashidx");
         }
@@ -2709,9 +2709,9 @@ struct MsdRunner {
             if (nb1 > 1 || ranged) {
                 const double hb = from_reads ? (double)rd->n_words * 8 : (double)N * rec;
                 if (from_reads) {
-                    launch_part_reads<false, true>("part_hist1_reads", hb, ntiles1h, Sh, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+                    launch_part_reads<false, true>("k_part_reads_hist", hb, ntiles1h, Sh, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
                 } else {
-                    launch_part<false, true>("part_hist1_keys", hb, ntiles1, kin, nullptr, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
+                    launch_part<false, true>("k_part_hist1", hb, ntiles1, kin, nullptr, M1, L1, hist1.as<uint32_t>(), nullptr, nullptr, nullptr);
                 }
             } else {
                 const uint32_t n32 = (uint32_t)N;
@@ -2748,7 +2748,7 @@ struct MsdRunner {
                 if constexpr (W == 1) {
                     const double pbn = (double)rd->n_words * 8 + (double)N * (4 + (has_val ? 4 : 0));
                     const size_t sm = part_reads_narrow_smem(has_val);
-                    KernelTimer t(ctx, "part_scatter1_reads", pbn);
+                    KernelTimer t(ctx, "k_part_reads_narrow", pbn);
                     if (has_val) {
                         auto fn = k_part_reads_narrow<true>;
                         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
@@ -2761,11 +2761,11 @@ struct MsdRunner {
                     check_launch("k_part_reads_narrow");
                 }
             } else if (from_reads) {
-                if (has_val) launch_part_reads<true, false>("part_scatter1_reads", pb, ntiles1, S, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
-                else launch_part_reads<false, false>("part_scatter1_reads", pb, ntiles1, S, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
+                if (has_val) launch_part_reads<true, false>("k_part_reads", pb, ntiles1, S, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
+                else launch_part_reads<false, false>("k_part_reads", pb, ntiles1, S, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
             } else {
-                if (has_val) launch_part<true, false>("part_scatter1_keys", pb, ntiles1, kin, d_vals, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
-                else launch_part<false, false>("part_scatter1_keys", pb, ntiles1, kin, nullptr, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
+                if (has_val) launch_part<true, false>("k_part_l1", pb, ntiles1, kin, d_vals, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), valA.as<uint32_t>());
+                else launch_part<false, false>("k_part_l1", pb, ntiles1, kin, nullptr, M1, L1, nullptr, cur1.as<uint32_t>(), bufA.as<Key<W>>(), nullptr);
             }
         }
         if (slots) {
@@ -2783,6 +2783,22 @@ struct MsdRunner {
                 } else {
                     h1[b] = reserved;
                 }
+            }
+            if (got > Ntot) {  // cannot be: every instance reserves one place.  Say what was read before failing
+                std::vector<uint32_t> c2(nb1);
+                BBK_HIP(hipMemcpyAsync(c2.data(), cur1.p, (size_t)nb1 * 4, hipMemcpyDeviceToHost, ctx->stream));
+                BBK_HIP(hipStreamSynchronize(ctx->stream));
+                uint32_t shown = 0, differ = 0;
+                for (uint32_t b = 0; b < nb1; ++b) differ += c1[b] != c2[b];
+                for (uint32_t b = 0; b < nb1 && shown < 8; ++b)
+                    if (c1[b] - off1[b] > 2 * seg_cap) {
+                        fprintf(stderr, "[bbk] level-1 cursor %u: start %u now %u (second read %u), slot capacity %u\n", b,
+                                off1[b], c1[b], c2[b], seg_cap);
+                        ++shown;
+                    }
+                fprintf(stderr, "[bbk] level-1 cursors: %u of %u differ between two reads; cur1 at %p\n", differ, nb1, cur1.p);
+                BBK_REQUIRE(false, BBK_ERR_INTERNAL, "level-1 reservations exceed the instance space (%llu vs %llu)",
+                            (unsigned long long)got, (unsigned long long)Ntot);
             }
             if (ranged) {
                 N = got;
@@ -2838,7 +2854,7 @@ struct MsdRunner {
         if (need_vbuf) valB.alloc(nB * 4);
         if (!slots) {
             BBK_HIP(hipMemsetAsync(hist2.p, 0, (size_t)nbuckets * 4 + 16, ctx->stream));
-            launch_part<false, true>("part_hist2", (double)N * rec, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2,
+            launch_part<false, true>("k_part_hist2", (double)N * rec, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2,
                                      hist2.as<uint32_t>(), nullptr, nullptr, nullptr);
             DevBuf h64(((size_t)nbuckets + 1) * 8);
             hipLaunchKernelGGL(k_u32_to_u64, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream,
@@ -2868,7 +2884,7 @@ struct MsdRunner {
             if (ntiles2) {
                 const double pb = 2.0 * (double)N * (4 + (has_val ? 4 : 0));
                 const size_t sm = part_narrow2_smem(has_val);
-                KernelTimer t(ctx, "part_scatter2", pb);
+                KernelTimer t(ctx, "k_part_narrow2", pb);
                 if (has_val) {
                     auto fn = k_part_narrow2<true>;
                     BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
@@ -2884,8 +2900,8 @@ struct MsdRunner {
             }
         } else {
             const double pb = 2.0 * (double)N * (rec + (has_val ? 4 : 0));
-            if (has_val) launch_part<true, false>("part_scatter2", pb, ntiles2, bufA.as<Key<W>>(), valA.as<uint32_t>(), M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), valB.as<uint32_t>());
-            else launch_part<false, false>("part_scatter2", pb, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), nullptr);
+            if (has_val) launch_part<true, false>("k_part_l2", pb, ntiles2, bufA.as<Key<W>>(), valA.as<uint32_t>(), M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), valB.as<uint32_t>());
+            else launch_part<false, false>("k_part_l2", pb, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), nullptr);
         }
 
         // ---- buckets in LDS
@@ -2953,7 +2969,7 @@ struct MsdRunner {
                 const double bbn = (double)N * (4 + (has_val ? 4 : 0));
                 auto launch32 = [&](auto fn, size_t sm) {
                     BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-                    KernelTimer t(ctx, "lds_dedup", bbn);
+                    KernelTimer t(ctx, "k_bucket_hash32", bbn);
                     hipLaunchKernelGGL(fn, dim3(nbuckets), dim3(kNwHashThreads), sm, ctx->stream, bufB.as<uint32_t>(),
                                        valB.as<uint32_t>(), A, bseg.as<uint16_t>(), nw_hb);
                     check_launch("k_bucket_hash32");
@@ -3275,7 +3291,7 @@ struct MsdRunner {
         const uint64_t nt = (n_records + kPartTileK - 1) / kPartTileK;
         BBK_REQUIRE(nt < (1ull << 32), BBK_ERR_ARG, "input of %llu records exceeds the tile space", (unsigned long long)n_records);
         const size_t rec = (size_t)W * 8;
-        launch_part<false, true>("part_hist0", (double)(expand_k ? n_records / 2 : n_records) * rec, (uint32_t)nt,
+        launch_part<false, true>("k_part_hist0", (double)(expand_k ? n_records / 2 : n_records) * rec, (uint32_t)nt,
                                  (const Key<W> *)d_keys, nullptr, M, L, h.as<uint32_t>(), nullptr, nullptr, nullptr);
         std::vector<uint32_t> h32(nb);
         BBK_HIP(hipMemcpyAsync(h32.data(), h.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -3475,10 +3491,10 @@ struct MsdRunner {
             TileMap M0{nullptr, nullptr, nullptr, 1, Ntot, 0, 1, nullptr, (int)ek, et ? 1 : 0};
             const double pb = (double)(ek ? n_in : Ntot) * (rec + (has_val ? 4 : 0)) + (double)nc * (rec + (has_val ? 4 : 0));
             if (has_val)
-                launch_part<true, false>("part_scatter0_keys", pb, (uint32_t)nt, (const Key<W> *)d_keys, d_vals, M0, L0, nullptr,
+                launch_part<true, false>("k_part_l0", pb, (uint32_t)nt, (const Key<W> *)d_keys, d_vals, M0, L0, nullptr,
                                          cur.as<uint32_t>(), buf0.as<Key<W>>(), val0.as<uint32_t>());
             else
-                launch_part<false, false>("part_scatter0_keys", pb, (uint32_t)nt, (const Key<W> *)d_keys, nullptr, M0, L0, nullptr,
+                launch_part<false, false>("k_part_l0", pb, (uint32_t)nt, (const Key<W> *)d_keys, nullptr, M0, L0, nullptr,
                                           cur.as<uint32_t>(), buf0.as<Key<W>>(), nullptr);
             std::vector<uint32_t> end(m);
             BBK_HIP(hipMemcpyAsync(end.data(), cur.p, m * 4, hipMemcpyDeviceToHost, ctx->stream));

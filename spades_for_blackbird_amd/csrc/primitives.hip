@@ -17,8 +17,10 @@
 #include <cstdarg>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 #include "arena.h"
 #include "bbk_internal.h"
@@ -44,6 +46,14 @@ const char *get_error() { return g_err; }
 // with coalescing inside the range.  Physical memory is paid for once; every later request of any size is carved out
 // of what is already mapped.  (Fallback when the virtual-memory API is unavailable: the size-matching block cache.)
 //
+// bbk_ctx_trim / context destruction unmap and release the chunks at the end of the arena that are entirely free.
+// A virtual address that was unmapped is never mapped again (arena.h: ArenaIndex::top only grows): on this platform a
+// range that is unmapped and then given NEW physical memory is not coherent afterwards -- a kernel that fills and
+// re-reads it finds words of the wrong chunk, a small host->device copy does not arrive where the next kernel reads
+// (tools/probes/vmm_remap_copy_probe.hip, profiles/r03/vmm_remap_probe.log; the round-2 "abort after trim").  New
+// chunks at fresh addresses are clean.  When the reserved range is used up the arena gets a new GENERATION (another
+// reservation); an old generation only takes its blocks back and disappears when the last one has returned.
+//
 // Keys are (device, host thread).  The ABI's contract is one context per GPU per host thread, all of a context's work
 // is issued on its one stream, and every entry point returns with that stream idle or with the released blocks' last
 // use already queued on it -- so inside one key, handing released memory to the next request is stream-ordered.
@@ -56,21 +66,25 @@ struct PoolKey {
 };
 constexpr size_t kPoolGranule = 2ull << 20;   // request sizes are rounded to 2 MiB
 constexpr size_t kArenaChunk = 1ull << 30;    // physical memory is mapped in 1 GiB chunks
-constexpr size_t kArenaVA = 1ull << 40;       // reserved virtual range per arena (1 TiB)
 
 struct Arena : ArenaIndex {  // bookkeeping in arena.h (host-only, fuzzed by tests/test_arena.py)
     char *base = nullptr;
-    std::vector<hipMemGenericAllocationHandle_t> chunks;
+    size_t va_bytes = 0;  // size of the reservation
+    std::vector<hipMemGenericAllocationHandle_t> chunks;  // parallel to chunk_off
+    bool contains(const void *p) const { return base && (const char *)p >= base && (const char *)p < base + va_bytes; }
+};
+struct ArenaGens {
+    std::vector<std::unique_ptr<Arena>> gens;  // the last one serves requests
 };
 
 struct Pool {
     std::mutex mu;
     int vmm = -1;  // -1 undecided, 0 block cache, 1 arenas
-    std::map<PoolKey, Arena> arenas;
+    std::map<PoolKey, ArenaGens> arenas;
     std::map<PoolKey, std::multimap<size_t, void *>> free_blocks;  // block-cache fallback: key -> size -> block
     // statistics (BBK_VERBOSE prints them when a context is destroyed)
     double malloc_s = 0, free_s = 0;
-    uint64_t mallocs = 0, frees = 0, hits = 0;
+    uint64_t mallocs = 0, frees = 0, hits = 0, generations = 0;
     double malloc_bytes = 0;
 };
 inline double wall_s() {
@@ -86,21 +100,50 @@ int current_device() {
     return d;
 }
 
-// unmaps and releases the chunks at the END of the mapped range that are completely free (all of them when nothing
-// is allocated); caller holds the lock and has made sure the device is idle.
+// reservation of a new generation: as large as the platform grants (BBK_ARENA_VA_GB: tests make it small)
+std::unique_ptr<Arena> arena_reserve() {
+    auto A = std::make_unique<Arena>();
+    const char *e = getenv("BBK_ARENA_VA_GB");
+    const size_t first = e ? (size_t)strtoull(e, nullptr, 10) << 30 : (16ull << 40);
+    for (size_t sz = first; sz >= (e ? first : (1ull << 38)); sz >>= 1) {
+        void *p = nullptr;
+        if (hipMemAddressReserve(&p, sz, 0, nullptr, 0) == hipSuccess && p) {
+            A->base = (char *)p;
+            A->va_bytes = sz;
+            ++pool().generations;
+            return A;
+        }
+        (void)hipGetLastError();
+        if (e) break;
+    }
+    return nullptr;
+}
+
+// unmaps and releases the chunks at the END of the backed range that are completely free (all of them when nothing
+// is allocated); caller holds the lock and has made sure the device is idle.  Their addresses are retired.
 void arena_shrink(Arena &A) {
     const double t0 = wall_s();
-    (void)hipDeviceSynchronize();
-    while (!A.chunks.empty() && A.shrink_one(kArenaChunk)) {
-        (void)hipMemUnmap(A.base + A.mapped, kArenaChunk);  // shrink_one has already lowered `mapped` by one chunk
-        (void)hipMemRelease(A.chunks.back());
+    size_t at = 0;
+    while (!A.chunks.empty() && A.shrink_one(kArenaChunk, &at)) {
+        const hipError_t eu = hipMemUnmap(A.base + at, kArenaChunk);
+        if (eu != hipSuccess) {  // still mapped, but no longer in the index: the chunk is lost to this arena, not reused
+            fprintf(stderr, "[bbk] arena: hipMemUnmap(+%zu GiB) failed: %s\n", at >> 30, hipGetErrorString(eu));
+            (void)hipGetLastError();
+        } else {
+            const hipError_t er = hipMemRelease(A.chunks.back());
+            if (er != hipSuccess) {
+                fprintf(stderr, "[bbk] arena: hipMemRelease failed: %s\n", hipGetErrorString(er));
+                (void)hipGetLastError();
+            }
+        }
         A.chunks.pop_back();
         ++pool().frees;
     }
     pool().free_s += wall_s() - t0;
 }
 
-// maps `n` more chunks at the end of the arena; false on out-of-memory (nothing is left half-mapped)
+// maps `n` more chunks at the top of the arena; false on out-of-memory or when the reservation is used up (nothing is
+// left half-mapped: the chunks that were mapped stay and are usable)
 bool arena_grow(Arena &A, int dev, size_t n) {
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned;
@@ -112,11 +155,11 @@ bool arena_grow(Arena &A, int dev, size_t n) {
     const double t0 = wall_s();
     size_t done = 0;
     for (; done < n; ++done) {
-        if (A.mapped + kArenaChunk > kArenaVA) break;
+        if (A.top + kArenaChunk > A.va_bytes) break;
         hipMemGenericAllocationHandle_t h;
         if (hipMemCreate(&h, kArenaChunk, &prop, 0) != hipSuccess) break;
-        if (hipMemMap(A.base + A.mapped, kArenaChunk, 0, h, 0) != hipSuccess ||
-            hipMemSetAccess(A.base + A.mapped, kArenaChunk, &acc, 1) != hipSuccess) {
+        if (hipMemMap(A.base + A.top, kArenaChunk, 0, h, 0) != hipSuccess ||
+            hipMemSetAccess(A.base + A.top, kArenaChunk, &acc, 1) != hipSuccess) {
             (void)hipMemRelease(h);
             break;
         }
@@ -141,17 +184,41 @@ void trim_device_blocks(int device) {
         kv.second.clear();
     }
 }
+
+// trims every generation of a key; generations other than the serving one go away once nothing is backed in them
+// (their reservation stays reserved: a freed range could be handed out again by the driver -- the reuse to avoid)
+void gens_shrink(ArenaGens &G) {
+    for (size_t i = 0; i < G.gens.size();) {
+        arena_shrink(*G.gens[i]);
+        if (i + 1 < G.gens.size() && G.gens[i]->mapped == 0) G.gens.erase(G.gens.begin() + (long)i);
+        else ++i;
+    }
+}
 }  // namespace
 
 void pool_report() {
     std::lock_guard<std::mutex> g(pool().mu);
-    size_t mapped = 0;
-    for (auto &kv : pool().arenas) mapped += kv.second.mapped;
+    size_t mapped = 0, retired = 0;
+    for (auto &kv : pool().arenas)
+        for (auto &A : kv.second.gens) {
+            mapped += A->mapped;
+            retired += A->top - A->mapped;
+        }
     fprintf(stderr, "[bbk] allocator (%s): %llu %s (%.1f GB, %.3f s), %llu requests served from mapped memory, %llu releases "
-                    "(%.3f s), %.1f GB mapped now\n",
+                    "(%.3f s), %.1f GB mapped now, %.1f GB of addresses retired, %llu reservation(s)\n",
             pool().vmm == 1 ? "arena" : "block cache", (unsigned long long)pool().mallocs,
             pool().vmm == 1 ? "chunks mapped" : "hipMalloc", pool().malloc_bytes / 1e9, pool().malloc_s,
-            (unsigned long long)pool().hits, (unsigned long long)pool().frees, pool().free_s, (double)mapped / 1e9);
+            (unsigned long long)pool().hits, (unsigned long long)pool().frees, pool().free_s, (double)mapped / 1e9,
+            (double)retired / 1e9, (unsigned long long)pool().generations);
+}
+
+size_t pool_mapped_bytes(int device) {
+    std::lock_guard<std::mutex> g(pool().mu);
+    size_t mapped = 0;
+    for (auto &kv : pool().arenas)
+        if (kv.first.device == device)
+            for (auto &A : kv.second.gens) mapped += A->mapped;
+    return mapped;
 }
 
 static void *pool_alloc_impl(size_t bytes, size_t *granted, int *device);
@@ -177,53 +244,68 @@ static void *pool_alloc_impl(size_t bytes, size_t *granted, int *device) {
     std::unique_lock<std::mutex> g(pool().mu);
     if (pool().vmm == -1) pool().vmm = getenv("BBK_NO_VMM") ? 0 : 1;
     if (pool().vmm == 1) {
-        Arena &A = pool().arenas[key];
-        if (!A.base) {
-            void *p = nullptr;
-            if (hipMemAddressReserve(&p, kArenaVA, 0, nullptr, 0) != hipSuccess || !p) {
-                (void)hipGetLastError();
-                pool().vmm = pool().arenas.size() > 1 ? 1 : 0;  // no virtual-memory API on this platform: block cache
+        ArenaGens &G = pool().arenas[key];
+        if (G.gens.empty()) {
+            auto A = arena_reserve();
+            if (!A) {
+                bool others = false;
+                for (auto &kv : pool().arenas) others = others || !kv.second.gens.empty();
                 pool().arenas.erase(key);
-                if (pool().vmm == 1) {
+                if (others) {
                     set_error("hipMemAddressReserve failed");
                     throw Error{BBK_ERR_HIP};
                 }
+                pool().vmm = 0;  // no virtual-memory API on this platform: block cache
             } else {
-                A.base = (char *)p;
+                G.gens.push_back(std::move(A));
             }
         }
     }
     if (pool().vmm == 1) {
-        Arena &A = pool().arenas[key];
-        size_t off = 0;
-        if (A.take(want, &off)) {
-            ++pool().hits;
-            *granted = want;
-            return A.base + off;
-        }
-        // grow: the request may start in the free tail of the mapped range
-        const size_t need = (want - A.free_tail() + kArenaChunk - 1) / kArenaChunk;
-        if (!arena_grow(A, dev, need)) {
-            // out of device memory: give back what other arenas of this device hold unused, and our own free tail
-            // (their owners' streams may still have the last use of that memory queued: wait for the device first)
-            (void)hipDeviceSynchronize();
-            if (getenv("BBK_ARENA_UNMAP"))
-                for (auto &kv : pool().arenas)
-                    if (kv.first.device == dev && &kv.second != &A) arena_shrink(kv.second);
-            const size_t tail2 = A.free_tail();
-            const size_t need2 = want > tail2 ? (want - tail2 + kArenaChunk - 1) / kArenaChunk : 0;
-            if (!arena_grow(A, dev, need2)) {
-                set_error("device memory exhausted: %zu bytes requested, %.1f GB mapped, %.1f GB of it free but fragmented",
-                          want, (double)A.mapped / 1e9, (double)A.free_bytes() / 1e9);
-                throw Error{BBK_ERR_NOMEM};
+        ArenaGens &G = pool().arenas[key];
+        for (int attempt = 0;; ++attempt) {
+            Arena &A = *G.gens.back();
+            size_t off = 0;
+            if (A.take(want, &off)) {
+                ++pool().hits;
+                *granted = want;
+                return A.base + off;
             }
+            // grow: the request may start in the free tail of the backed range
+            const size_t tail = A.free_tail();
+            const size_t need = (want - tail + kArenaChunk - 1) / kArenaChunk;
+            if (A.top + need * kArenaChunk > A.va_bytes) {
+                // the reservation is used up (retired addresses are not reused): a new generation serves from here on
+                BBK_REQUIRE(attempt == 0 && want + kArenaChunk <= A.va_bytes, BBK_ERR_NOMEM,
+                            "request of %zu bytes does not fit a reservation of %zu", want, A.va_bytes);
+                auto N = arena_reserve();
+                BBK_REQUIRE(N != nullptr, BBK_ERR_HIP, "hipMemAddressReserve failed for a new arena generation");
+                G.gens.push_back(std::move(N));
+                continue;
+            }
+            if (!arena_grow(A, dev, need)) {
+                // out of device memory: give back what the arenas of this device hold unused -- other threads' and our
+                // own free chunks (their owners' streams may still have the last use of that memory queued: wait for
+                // the device first)
+                (void)hipDeviceSynchronize();
+                for (auto &kv : pool().arenas)
+                    if (kv.first.device == dev) gens_shrink(kv.second);
+                Arena &B = *G.gens.back();
+                const size_t tail2 = B.free_tail();
+                const size_t need2 = want > tail2 ? (want - tail2 + kArenaChunk - 1) / kArenaChunk : 0;
+                if (B.top + need2 * kArenaChunk > B.va_bytes || !arena_grow(B, dev, need2)) {
+                    set_error("device memory exhausted: %zu bytes requested, %.1f GB mapped, %.1f GB of it free but fragmented",
+                              want, (double)B.mapped / 1e9, (double)B.free_bytes() / 1e9);
+                    throw Error{BBK_ERR_NOMEM};
+                }
+            }
+            if (!G.gens.back()->take(want, &off)) {
+                set_error("arena: internal error after growing");
+                throw Error{BBK_ERR_INTERNAL};
+            }
+            *granted = want;
+            return G.gens.back()->base + off;
         }
-        if (!A.take(want, &off)) {
-            set_error("arena: internal error after growing");
-            throw Error{BBK_ERR_INTERNAL};
-        }
-        *granted = want;
-        return A.base + off;
     }
     // ---- block-cache fallback
     {
@@ -261,14 +343,15 @@ void pool_free(void *p, size_t bytes, int device) {
     std::lock_guard<std::mutex> g(pool().mu);
     const PoolKey key{device, std::this_thread::get_id()};
     if (pool().vmm == 1) {
-        // the block returns to the arena it came from: the one of this (device, thread), or -- a handle released by
-        // another thread -- whichever arena of the device contains the address
+        // the block returns to the arena it came from: a generation of this (device, thread), or -- a handle released
+        // by another thread -- whichever arena of the device contains the address
         for (auto &kv : pool().arenas) {
-            Arena &A = kv.second;
-            if (kv.first.device == device && A.base && (char *)p >= A.base && (char *)p < A.base + kArenaVA) {
-                A.add_free((size_t)((char *)p - A.base), bytes);
-                return;
-            }
+            if (kv.first.device != device) continue;
+            for (auto &A : kv.second.gens)
+                if (A->contains(p)) {
+                    A->add_free((size_t)((char *)p - A->base), bytes);
+                    return;
+                }
         }
         return;  // not ours (cannot happen)
     }
@@ -276,17 +359,16 @@ void pool_free(void *p, size_t bytes, int device) {
 }
 
 // gives the unused memory of this (device, calling thread) back to the driver: what a context being destroyed (or
-// bbk_ctx_trim) leaves behind
+// bbk_ctx_trim) leaves behind.  The caller has drained the context's stream; the device is synchronised here because
+// unmapping under a running kernel of another stream would fault it.
 void pool_trim(int device) {
     std::lock_guard<std::mutex> g(pool().mu);
     const PoolKey key{device, std::this_thread::get_id()};
     if (pool().vmm == 1) {
         auto it = pool().arenas.find(key);
-        // Mapped chunks are NOT handed back by default: on this platform unmapping chunks and later mapping new ones
-        // into the same virtual range ended in a GPU memory fault (tests/test_gpu_configs2.py aborted at its second
-        // trim; with the chunks kept it passes) -- stale translations survive hipMemUnmap.  An arena therefore keeps its
-        // high-water mark for the life of the process; BBK_ARENA_UNMAP=1 re-enables the release for experiments.
-        if (it != pool().arenas.end() && getenv("BBK_ARENA_UNMAP")) arena_shrink(it->second);
+        if (it == pool().arenas.end() || getenv("BBK_ARENA_KEEP")) return;  // BBK_ARENA_KEEP=1: A/B switch, never unmap
+        (void)hipDeviceSynchronize();
+        gens_shrink(it->second);
         return;
     }
     auto it = pool().free_blocks.find(key);

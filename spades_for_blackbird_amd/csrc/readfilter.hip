@@ -17,29 +17,15 @@
 
 namespace bbk {
 
-unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsigned k, uint64_t n, DevBuf &prefix);
-
-template <int W>
-__device__ inline uint32_t rf_find(const Key<W> *__restrict__ keys, const uint32_t *__restrict__ pref, int pshift,
-                                   const Key<W> &q) {
-    const uint32_t t = (uint32_t)(q.w[0] >> pshift);
-    uint32_t lo = pref[t], hi = pref[t + 1];
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        const Key<W> km = key_load<W>(&keys[mid]);
-        if (key_eq<W>(km, q)) return mid;
-        if (key_less_words<W>(km, q)) lo = mid + 1;
-        else hi = mid;
-    }
-    return 0xFFFFFFFFu;
-}
+unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsigned k, uint64_t n, DevBuf &prefix,
+                            bool *wide);
 
 // one wavefront per read, lanes over its k-mer positions
 template <int W>
 __global__ __launch_bounds__(256) void k_median_filter(const uint64_t *__restrict__ words, const uint64_t *__restrict__ woff,
                                                       const uint32_t *__restrict__ len, uint64_t n_reads, int k,
                                                       const Key<W> *__restrict__ keys, const uint32_t *__restrict__ counts,
-                                                      const uint32_t *__restrict__ pref, int pshift, uint32_t threshold,
+                                                      PrefixTable P, uint32_t threshold,
                                                       uint8_t *__restrict__ keep) {
     const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= n_reads) return;
@@ -56,8 +42,8 @@ __global__ __launch_bounds__(256) void k_median_filter(const uint64_t *__restric
         const Key<W> f = kmer_extract<W>(rw, p, k);
         const Key<W> rc = kmer_rc<W>(f, k);
         const Key<W> c = key_select<W>(!kmer_less_nucl<W>(rc, f), f, rc);
-        const uint32_t i = rf_find<W>(keys, pref, pshift, c);
-        const uint32_t m = i == 0xFFFFFFFFu ? 0u : counts[i];
+        const uint64_t i = table_find<W>(keys, P, c);
+        const uint32_t m = i == kNotFound ? 0u : counts[i];
         ge += m >= threshold ? 1u : 0u;
     }
 #pragma unroll
@@ -68,12 +54,13 @@ __global__ __launch_bounds__(256) void k_median_filter(const uint64_t *__restric
 template <int W>
 static void median_filter_impl(bbk_ctx *ctx, const bbk_reads *rd, const bbk_kmerset *s, uint32_t threshold, uint8_t *d_keep) {
     DevBuf prefix;
-    const unsigned bits = build_prefix_index(ctx, s->keys.as<uint64_t>(), s->W, s->k, s->n, prefix);
+    bool wide = false;
+    const unsigned bits = build_prefix_index(ctx, s->keys.as<uint64_t>(), s->W, s->k, s->n, prefix, &wide);
     const int w0bits = (W == 1) ? (int)(2 * s->k) : 64;
     const uint64_t threads = rd->n * 64;
     hipLaunchKernelGGL(k_median_filter<W>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, rd->d_words,
                        rd->d_woff, rd->d_len, rd->n, (int)s->k, s->keys.as<Key<W>>(), s->counts.as<uint32_t>(),
-                       prefix.as<uint32_t>(), w0bits - (int)bits, threshold, d_keep);
+                       PrefixTable{prefix.p, w0bits - (int)bits, wide ? 1 : 0}, threshold, d_keep);
     check_launch("k_median_filter");
     BBK_HIP(hipStreamSynchronize(ctx->stream));
 }

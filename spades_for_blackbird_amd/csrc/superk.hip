@@ -884,7 +884,7 @@ void launch_dedup_g(bbk_ctx *ctx, const char *fam, uint32_t nblocks, const SkPar
 // second == 0: all buckets, first geometry (failures are listed); else the `second` listed buckets, big geometry
 template <int W>
 void launch_dedup(bbk_ctx *ctx, int op, uint32_t nbuckets, uint32_t second, const SkParams &P, const SkDedupArgs &A, double bytes) {
-    const char *fam = second ? "sk_dedup2" : "sk_dedup";
+    const char *fam = second ? "k_sk_dedup_B" : "k_sk_dedup";
 #define BBK_SK_DEDUP(OPV)                                                                                    \
     if (second) launch_dedup_g<W, OPV, SkdB>(ctx, fam, second, P, A, A.fail_list, A.fail2_list, (uint32_t)SKF_NFAIL2, bytes); \
     else launch_dedup_g<W, OPV, SkdA>(ctx, fam, nbuckets, P, A, nullptr, A.fail_list, (uint32_t)SKF_NFAIL, bytes)
@@ -1050,13 +1050,13 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
         BBK_HIP(hipMemsetAsync(cur1.p, 0, (size_t)P1 * 4, ctx->stream));
         BBK_HIP(hipMemsetAsync(boff.p, 0, (size_t)(nbuckets + 1) * 8, ctx->stream));
         {
-            KernelTimer t(ctx, "sk_part1", (double)rd->n_words * 8 + est_pass * rec_bytes);
+            KernelTimer t(ctx, "k_sk_part1", (double)rd->n_words * 8 + est_pass * rec_bytes);
             hipLaunchKernelGGL(k_sk_part1<RW>, dim3((unsigned)ntiles1), dim3(kSk1NT), sm1, ctx->stream, S, P, cur1.as<uint32_t>(),
                                buf1.as<uint64_t>(), spill.as<uint64_t>(), dflags.as<uint32_t>());
             check_launch("k_sk_part1");
         }
         {
-            KernelTimer t(ctx, "sk_hist2", est_pass * rec_bytes);
+            KernelTimer t(ctx, "k_sk_part2_hist", est_pass * rec_bytes);
             hipLaunchKernelGGL((k_sk_part2<RW, true>), dim3(P1 * P.tps), dim3(kSk2NT), 0, ctx->stream, buf1.as<uint64_t>(), P,
                                cur1.as<uint32_t>(), boff.as<unsigned long long>(), (uint64_t *)nullptr, dflags.as<uint32_t>());
             check_launch("k_sk_hist2");
@@ -1082,16 +1082,17 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
             buf2.alloc((size_t)((double)(n_rec + 1) * (np > 1 ? 1.05 : 1.0)) * rec_bytes);
         }
         {
-            KernelTimer t(ctx, "sk_part2", 2.0 * (double)n_rec * rec_bytes);
+            KernelTimer t(ctx, "k_sk_part2", 2.0 * (double)n_rec * rec_bytes);
             hipLaunchKernelGGL((k_sk_part2<RW, false>), dim3(P1 * P.tps), dim3(kSk2NT), 0, ctx->stream, buf1.as<uint64_t>(), P,
                                cur1.as<uint32_t>(), cur2.as<unsigned long long>(), buf2.as<uint64_t>(), dflags.as<uint32_t>());
             check_launch("k_sk_part2");
         }
         ctx->add_stat("stat_superk_records", (double)n_rec);
         for (int attempt = 0;; ++attempt) {
-            // algorithmic bytes: the records read + the distinct keys written (their number is only known afterwards:
-            // the planning multiplicity stands in)
-            const double db = (double)n_rec * rec_bytes + (double)N / np / dup_plan * (key_bytes + (op != MSD_OP_NONE ? 4 : 0));
+            // algorithmic bytes: the records read + the distinct keys written; their number is known once the cursor has
+            // been read back (below) and is put into the timer's entry then
+            const double db = (double)n_rec * rec_bytes;
+            const size_t timer_entry = ctx->pending.size();
             SkDedupArgs A{n_spill ? hot.as<uint8_t>() : nullptr, fail2_list.as<uint32_t>(), buf2.as<uint64_t>(),
                           boff.as<unsigned long long>(), okeys.p, ovals.as<uint32_t>(), dcursor.as<unsigned long long>(), out_cap,
                           dflags.as<uint32_t>(), fail_list.as<uint32_t>()};
@@ -1102,6 +1103,8 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
             BBK_HIP(hipMemcpyAsync(hflags, dflags.p, 64, hipMemcpyDeviceToHost, ctx->stream));
             BBK_HIP(hipMemcpyAsync(&cursor_now, dcursor.p, 8, hipMemcpyDeviceToHost, ctx->stream));
             BBK_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->profiling && ctx->pending.size() > timer_entry && cursor_now >= done_before)
+                ctx->pending[timer_entry].bytes += (double)(cursor_now - done_before) * (key_bytes + (op != MSD_OP_NONE ? 4 : 0));
             if (hflags[SKF_NFAIL] && !hflags[SKF_OUT]) {  // second chance for the buckets the small table gave up
                 if (hflags[SKF_NFAIL] > kSkdFailCap) return declined(pass);
                 if (verbose)
@@ -1142,7 +1145,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
                 BBK_HIP(hipMemsetAsync(fb_total.p, 0, 16, ctx->stream));
                 auto expand = [&](const uint64_t *recs, const uint32_t *ids, uint32_t nblocks, uint32_t n_flat) {
                     if (nblocks == 0) return;
-                    KernelTimer t(ctx, "sk_expand", 0);
+                    KernelTimer t(ctx, "k_sk_expand", 0);
                     if (op == MSD_OP_OR)
                         hipLaunchKernelGGL((k_sk_expand<W, 3>), dim3(nblocks), dim3(256), 0, ctx->stream, recs, boff.as<unsigned long long>(),
                                            ids, n_flat, P, fk.as<Key<W>>(), fv.as<uint32_t>(), fb_total.as<unsigned long long>(),

@@ -23,32 +23,21 @@ namespace bbk {
 template <int W>
 struct Oriented {
     Key<W> key;    // the k-mer as oriented
-    uint32_t idx;  // table index of its canonical form
+    uint64_t idx;  // table index of its canonical form
     bool minimal;  // key is the canonical form
 };
 
 struct TipTable {
     const void *keys;
     const uint8_t *masks;
-    const uint32_t *pref;
-    int pshift;
+    PrefixTable P;
     int k;
     uint64_t n;
 };
 
 template <int W>
-__device__ inline uint32_t tt_find(const TipTable &T, const Key<W> &q) {
-    const Key<W> *keys = reinterpret_cast<const Key<W> *>(T.keys);
-    const uint32_t t = (uint32_t)(q.w[0] >> T.pshift);
-    uint32_t lo = T.pref[t], hi = T.pref[t + 1];
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        const Key<W> km = key_load<W>(&keys[mid]);
-        if (key_eq<W>(km, q)) return mid;
-        if (key_less_words<W>(km, q)) lo = mid + 1;
-        else hi = mid;
-    }
-    return 0xFFFFFFFFu;
+__device__ inline uint64_t tt_find(const TipTable &T, const Key<W> &q) {
+    return table_find<W>(reinterpret_cast<const Key<W> *>(T.keys), T.P, q);
 }
 
 // InvertableKeyWithHash (utils/ph_map/key_with_hash.hpp:108-207)
@@ -58,7 +47,7 @@ __device__ inline bool tt_orient(const TipTable &T, const Key<W> &key, Oriented<
     o.key = key;
     o.minimal = !kmer_less_nucl<W>(rc, key);  // IsMinimal (rtseq.hpp:407-415)
     o.idx = tt_find<W>(T, key_select<W>(o.minimal, key, rc));
-    return o.idx != 0xFFFFFFFFu;
+    return o.idx != kNotFound;
 }
 
 // InvertableStoring::get_value (storing_traits.hpp:30-68)
@@ -97,7 +86,7 @@ __global__ __launch_bounds__(256) void k_tips_find(TipTable T, uint32_t length_b
                                                   uint8_t *__restrict__ tipped, unsigned long long *__restrict__ removed) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * T.n) return;
-    const uint32_t i = (uint32_t)(t >> 1);
+    const uint64_t i = t >> 1;
     const bool rc_side = t & 1;
     const Key<W> canon = key_load<W>(&reinterpret_cast<const Key<W> *>(T.keys)[i]);
     const Key<W> key = key_select<W>(rc_side, kmer_rc<W>(canon, T.k), canon);
@@ -176,7 +165,8 @@ static void clip_tips_impl(bbk_ctx *ctx, bbk_extindex *x, uint32_t length_bound,
     BBK_HIP(hipMemsetAsync(flag.p, 0, x->n + 16, ctx->stream));
     BBK_HIP(hipMemsetAsync(tipped.p, 0, 2 * x->n + 16, ctx->stream));
     BBK_HIP(hipMemsetAsync(ctr.p, 0, 16, ctx->stream));
-    TipTable T{x->keys.p, x->masks.as<uint8_t>(), x->prefix.as<uint32_t>(), w0bits - (int)x->prefix_bits, (int)x->k, x->n};
+    TipTable T{x->keys.p, x->masks.as<uint8_t>(), PrefixTable{x->prefix.p, w0bits - (int)x->prefix_bits, x->prefix_wide ? 1 : 0},
+               (int)x->k, x->n};
     {
         KernelTimer t(ctx, "tip_find", 0.0);
         hipLaunchKernelGGL(k_tips_find<W>, dim3((unsigned)((2 * x->n + 255) / 256)), dim3(256), 0, ctx->stream, T,
@@ -206,7 +196,7 @@ extern "C" int bbk_extindex_clip_tips(bbk_ctx *ctx, bbk_extindex *x, uint32_t le
                                       uint64_t *removed_links) {
     return guarded([&] {
         BBK_REQUIRE(ctx && x, BBK_ERR_ARG, "bbk_extindex_clip_tips: NULL argument");
-        BBK_REQUIRE(x->n < (1ull << 32), BBK_ERR_ARG, "bbk_extindex_clip_tips: %llu k-mers exceed the 32-bit k-mer index",
+        BBK_REQUIRE(x->n < (1ull << 37), BBK_ERR_ARG, "bbk_extindex_clip_tips: %llu k-mers exceed the launch grid",
                     (unsigned long long)x->n);
         BBK_HIP(hipSetDevice(ctx->device));
         if (removed_kmers) *removed_kmers = 0;

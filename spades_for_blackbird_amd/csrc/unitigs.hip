@@ -33,7 +33,7 @@ struct bbk_unitigs {
     uint64_t n = 0, n_loops = 0, n_vertices = 0, n_links = 0;
     bbk::raw_vector<char> bases;        // concatenated ACGT
     bbk::raw_vector<uint64_t> offsets;  // n + 1
-    bbk::raw_vector<uint32_t> links;    // 2 per link: (from << 1 | from_plus), (to << 1 | to_plus)
+    bbk::raw_vector<uint64_t> links;    // 2 per link: (from << 1 | from_plus), (to << 1 | to_plus)
     bool has_cov = false;
     std::vector<uint64_t> kc;       // per unitig: sum of (k+1)-mer multiplicities (KC:i:)
     // Device-resident result (no perfect loops): the GFA text is formatted on the device and streamed
@@ -74,21 +74,6 @@ __global__ void k_fill_starts(const uint8_t *__restrict__ masks, uint64_t n, con
         if (mr & (1u << c)) starts[o++] = (i << 3) | 4u | c;
 }
 
-template <int W>
-__device__ inline uint32_t find_kmer(const Key<W> *__restrict__ keys, const uint32_t *__restrict__ pref, int pshift,
-                                     const Key<W> &q) {
-    const uint32_t t = (uint32_t)(q.w[0] >> pshift);
-    uint32_t lo = pref[t], hi = pref[t + 1];
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        const Key<W> km = key_load<W>(&keys[mid]);
-        if (key_eq<W>(km, q)) return mid;
-        if (key_less_words<W>(km, q)) lo = mid + 1;
-        else hi = mid;
-    }
-    return 0xFFFFFFFFu;
-}
-
 struct WalkOut {
     // pass 0
     uint64_t *keep;      // [E] 0/1
@@ -113,13 +98,13 @@ struct WalkOut {
 // by the same edge, the walk is deterministic, hence s == rc(s) (self-conjugate edge): keep.
 template <int W, int PASS>
 __global__ __launch_bounds__(256) void k_walk(const Key<W> *__restrict__ keys, const uint8_t *__restrict__ masks,
-                                             const uint32_t *__restrict__ pref, int pshift, uint64_t n, int k,
+                                             PrefixTable P, uint64_t n, int k,
                                              const uint64_t *__restrict__ starts, uint64_t E, WalkOut o) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     if (PASS == 1 && o.keep[e] == 0) return;
     const uint64_t d = starts[e];
-    const uint32_t i = (uint32_t)(d >> 3);
+    const uint64_t i = d >> 3;
     const bool s_rc = (d >> 2) & 1;
     const uint32_t c0 = (uint32_t)(d & 3);
     const Key<W> canon0 = key_load<W>(&keys[i]);
@@ -149,15 +134,15 @@ __global__ __launch_bounds__(256) void k_walk(const Key<W> *__restrict__ keys, c
     Key<W> cur = kmer_shl<W>(x, k, c0);
     uint64_t len = 1;
     uint32_t prev_first = kmer_base<W>(x, 0);
-    uint32_t j = 0xFFFFFFFFu;
+    uint64_t j = kNotFound;
     bool cur_min = true;
     Key<W> rcur = cur;
     for (;;) {
         rcur = kmer_rc<W>(cur, k);
         cur_min = !kmer_less_nucl<W>(rcur, cur);
         const Key<W> q = key_select<W>(cur_min, cur, rcur);
-        j = find_kmer<W>(keys, pref, pshift, q);
-        if (j == 0xFFFFFFFFu) {
+        j = table_find<W>(keys, P, q);
+        if (j == kNotFound) {
             atomicOr(o.err, 1u);
             return;
         }
@@ -191,8 +176,8 @@ __global__ __launch_bounds__(256) void k_walk(const Key<W> *__restrict__ keys, c
         o.uoff[u] = o.boff[e];
         const bool selfconj = key_eq<W>(x, rcur) && c0 == 3u - prev_first;
         // StartLink / EndLink (:432-448): canonical form of the end k-mers, is_rc = k-mer is not it
-        o.rec[2 * u] = ((uint64_t)i << 2) | ((uint64_t)(s_rc ? 1 : 0) << 1) | 1ull;
-        o.rec[2 * u + 1] = selfconj ? ~0ull : (((uint64_t)j << 2) | ((uint64_t)(cur_min ? 0 : 1) << 1));
+        o.rec[2 * u] = (i << 2) | ((uint64_t)(s_rc ? 1 : 0) << 1) | 1ull;
+        o.rec[2 * u + 1] = selfconj ? ~0ull : ((j << 2) | ((uint64_t)(cur_min ? 0 : 1) << 1));
         o.selfconj[u] = selfconj ? 1 : 0;
     }
 }
@@ -205,10 +190,50 @@ __global__ void k_loop_candidates(const uint8_t *__restrict__ masks, const uint8
 }
 
 __global__ void k_compact_candidates(const uint64_t *__restrict__ flag_scan, const uint8_t *__restrict__ masks,
-                                     const uint8_t *__restrict__ visited, uint64_t n, uint32_t *__restrict__ idx) {
+                                     const uint8_t *__restrict__ visited, uint64_t n, uint64_t *__restrict__ idx) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (!mask_is_junction(masks[i]) && !visited[i]) idx[flag_scan[i]] = (uint32_t)i;
+    if (!mask_is_junction(masks[i]) && !visited[i]) idx[flag_scan[i]] = i;
+}
+
+// unitigs -> packed reads (bbk_unitigs_to_reads): words per unitig, then one wavefront per unitig packs 32 bases per lane
+__global__ void k_unitig_words(const uint64_t *__restrict__ uoff, uint64_t nu, uint64_t *__restrict__ nw,
+                               uint32_t *__restrict__ len, uint32_t *__restrict__ err) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nu) return;
+    const uint64_t l = uoff[i + 1] - uoff[i];
+    if (l > 0xFFFFFFFFull) atomicOr(err, 1u);
+    len[i] = (uint32_t)l;
+    nw[i] = (l + 31) >> 5;
+}
+__global__ __launch_bounds__(256) void k_pack_unitigs(const char *__restrict__ bases, const uint64_t *__restrict__ uoff,
+                                                     const uint64_t *__restrict__ woff, uint64_t nu,
+                                                     uint64_t *__restrict__ words) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= nu) return;
+    const int lane = threadIdx.x & 63;
+    const uint64_t b0 = uoff[i], len = uoff[i + 1] - b0, nw = (len + 31) >> 5;
+    uint64_t *dst = words + woff[i];
+    for (uint64_t w = lane; w < nw; w += 64) {
+        const uint64_t lo = w << 5, hi = lo + 32 < len ? lo + 32 : len;
+        uint64_t v = 0;
+        for (uint64_t j = lo; j < hi; ++j) {
+            const char c = bases[b0 + j];
+            const uint64_t code = c == 'A' ? 0ull : c == 'C' ? 1ull : c == 'G' ? 2ull : 3ull;
+            v |= code << ((j - lo) << 1);
+        }
+        dst[w] = v;
+    }
+}
+
+__global__ void k_gather_candidates(const uint64_t *__restrict__ keys, const uint8_t *__restrict__ masks,
+                                    const uint64_t *__restrict__ idx, uint64_t nc, int W, uint64_t *__restrict__ out_keys,
+                                    uint8_t *__restrict__ out_masks) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nc) return;
+    const uint64_t r = idx[c];
+    for (int w = 0; w < W; ++w) out_keys[c * W + w] = keys[r * W + w];
+    out_masks[c] = masks[r];
 }
 
 // Links from the sorted link records (vertices = groups of equal canonical k-mer index): for every
@@ -228,7 +253,7 @@ template <bool WRITE>
 __global__ __launch_bounds__(256) void k_links(const uint64_t *__restrict__ key, const uint32_t *__restrict__ edge,
                                               uint64_t nrec, const uint8_t *__restrict__ selfconj,
                                               uint64_t *__restrict__ cnt, const uint64_t *__restrict__ off,
-                                              uint32_t *__restrict__ links, unsigned long long *__restrict__ nvert) {
+                                              uint64_t *__restrict__ links, unsigned long long *__restrict__ nvert) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrec) return;
     const uint64_t kr = key[r];
@@ -260,8 +285,8 @@ __global__ __launch_bounds__(256) void k_links(const uint64_t *__restrict__ key,
             if (!rec_outgoing(kb)) continue;
             const uint32_t eb = edge[b];
             const uint32_t ob = ((kb & 1) || selfconj[eb]) ? 1u : 0u;
-            links[2 * o] = (ea << 1) | oa;
-            links[2 * o + 1] = (eb << 1) | ob;
+            links[2 * o] = ((uint64_t)ea << 1) | oa;
+            links[2 * o + 1] = ((uint64_t)eb << 1) | ob;
             ++o;
         }
     }
@@ -295,7 +320,7 @@ static std::string unpack_kmer(const uint64_t *w, int k) {
 
 struct LoopTable {
     int k, W;
-    std::vector<uint32_t> idx;     // index in the full table
+    std::vector<uint64_t> idx;     // index in the full table
     std::vector<uint64_t> keys;    // W words each, ascending
     std::vector<uint8_t> masks;
     std::vector<uint8_t> used;
@@ -324,19 +349,17 @@ template <int W>
 static void run_walk(bbk_ctx *ctx, int pass, const bbk_extindex *x, const uint64_t *starts, uint64_t E, WalkOut o) {
     if (E == 0) return;
     const int w0bits = (x->W == 1) ? (int)(2 * x->k) : 64;
-    const int pshift = w0bits - (int)x->prefix_bits;
+    const PrefixTable P{x->prefix.p, w0bits - (int)x->prefix_bits, x->prefix_wide ? 1 : 0};
     // bytes: every non-junction k-mer is stepped over once per orientation; a step is one lookup = 2 prefix-table
     // entries + ~3 key probes + 1 mask byte (latency-bound pointer chase: the figure is for reading the rate, not a
     // roofline claim); pass 1 also writes the bases
     KernelTimer t(ctx, pass == 0 ? "walk0" : "walk1", 2.0 * (double)x->n * (3.0 * x->W * 8 + 8 + 1));
     if (pass == 0)
         hipLaunchKernelGGL((k_walk<W, 0>), dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ctx->stream,
-                           x->keys.as<Key<W>>(), x->masks.as<uint8_t>(), x->prefix.as<uint32_t>(), pshift, x->n,
-                           (int)x->k, starts, E, o);
+                           x->keys.as<Key<W>>(), x->masks.as<uint8_t>(), P, x->n, (int)x->k, starts, E, o);
     else
         hipLaunchKernelGGL((k_walk<W, 1>), dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ctx->stream,
-                           x->keys.as<Key<W>>(), x->masks.as<uint8_t>(), x->prefix.as<uint32_t>(), pshift, x->n,
-                           (int)x->k, starts, E, o);
+                           x->keys.as<Key<W>>(), x->masks.as<uint8_t>(), P, x->n, (int)x->k, starts, E, o);
     check_launch("k_walk");
 }
 
@@ -373,7 +396,7 @@ static void ensure_host(bbk_ctx *ctx, const bbk_unitigs *cu) {
     u->links.resize(2 * u->n_links);
     if (u->total_bases) d2h_big(ctx, u->bases.data(), u->d_bases.p, u->total_bases);
     d2h_big(ctx, u->offsets.data(), u->d_uoff.p, (u->n + 1) * 8);
-    if (u->n_links) d2h_big(ctx, u->links.data(), u->d_links.p, u->n_links * 8);
+    if (u->n_links) d2h_big(ctx, u->links.data(), u->d_links.p, u->n_links * 16);
     u->host_valid = true;
 }
 
@@ -421,28 +444,27 @@ __global__ __launch_bounds__(256) void k_gfa_s_write(const char *__restrict__ ba
     if (lane < (int)kGfaTail) sq[len + lane] = "\tDP:f:0\tKC:i:0\n"[lane];
 }
 
-__global__ void k_gfa_l_len(const uint32_t *__restrict__ links, uint64_t nl, uint32_t klen, uint64_t *__restrict__ len) {
+__global__ void k_gfa_l_len(const uint64_t *__restrict__ links, uint64_t nl, uint32_t klen, uint64_t *__restrict__ len) {
     const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l < nl)
-        len[l] = 2 + dev_dec_len(3 + 2 * (uint64_t)(links[2 * l] >> 1)) + 3 +
-                 dev_dec_len(3 + 2 * (uint64_t)(links[2 * l + 1] >> 1)) + 3 + klen + 2;
+        len[l] = 2 + dev_dec_len(3 + 2 * (links[2 * l] >> 1)) + 3 + dev_dec_len(3 + 2 * (links[2 * l + 1] >> 1)) + 3 + klen + 2;
 }
 
 // "L\t<e1>\t<+|->\t<e2>\t<+|->\t<k>M\n"
-__global__ void k_gfa_l_write(const uint32_t *__restrict__ links, const uint64_t *__restrict__ pos, uint64_t nl,
+__global__ void k_gfa_l_write(const uint64_t *__restrict__ links, const uint64_t *__restrict__ pos, uint64_t nl,
                               uint32_t k, uint32_t klen, char *__restrict__ out) {
     const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nl) return;
     char *d = out + pos[l];
-    const uint32_t a = links[2 * l], b = links[2 * l + 1];
-    const uint64_t ia = 3 + 2 * (uint64_t)(a >> 1), ib = 3 + 2 * (uint64_t)(b >> 1);
+    const uint64_t a = links[2 * l], b = links[2 * l + 1];
+    const uint64_t ia = 3 + 2 * (a >> 1), ib = 3 + 2 * (b >> 1);
     const uint32_t la = dev_dec_len(ia), lb = dev_dec_len(ib);
     *d++ = 'L';
     *d++ = '\t';
     dev_put_dec(d, ia, la);
     d += la;
     *d++ = '\t';
-    *d++ = (a & 1u) ? '+' : '-';
+    *d++ = (a & 1ull) ? '+' : '-';
     *d++ = '\t';
     dev_put_dec(d, ib, lb);
     d += lb;
@@ -460,7 +482,9 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     const uint64_t n = x->n;
     U.k = x->k;
     BBK_REQUIRE(k % 2 == 1, BBK_ERR_ARG, "k-mer size must be odd");  // projects/gbuilder/main.cpp:125-126
-    BBK_REQUIRE(n < (1ull << 32) - 2, BBK_ERR_ARG, "extension index too large for one device batch");
+    // k-mer indices, start edges and link-record keys are 64-bit (KMerIndex::seq_idx is a size_t, kmer_index.hpp:85-90;
+    // LinkRecord keys are 64-bit, debruijn_graph_constructor.hpp:400-430); only the launch grid bounds n
+    BBK_REQUIRE(n < (1ull << 37), BBK_ERR_ARG, "extension index of %llu k-mers exceeds the launch grid", (unsigned long long)n);
     U.offsets.assign(1, 0);
     if (n == 0) return;
     U.host_valid = true;
@@ -493,7 +517,8 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     uint32_t herr = 0;
     d2h(ctx, &herr, err.p, 4);
     BBK_REQUIRE(herr == 0, BBK_ERR_INTERNAL, "unitig walk failed (code %u): extension index is inconsistent", herr);
-    BBK_REQUIRE(NU < (1ull << 31), BBK_ERR_ARG, "too many unitigs for one device batch");
+    // edge ids travel as the u32 payload of the link-record sort, whose offsets are 32-bit: 2 NU < 2^32
+    BBK_REQUIRE(NU < (1ull << 31), BBK_ERR_ARG, "%llu unitigs: the link-record sort takes 2^31 - 1 edges", (unsigned long long)NU);
 
     // ---- pass 1: bases + link records
     DevBuf bases(NB + 16), uoff((NU + 1) * 8), rec((2 * NU + 2) * 8), selfc(NU + 16);
@@ -550,13 +575,13 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
             BBK_HIP(hipMemsetAsync(nv.p, 0, 16, ctx->stream));
             hipLaunchKernelGGL((k_links<false>), dim3((unsigned)((2 * NU + 255) / 256)), dim3(256), 0, ctx->stream,
                                rec.as<uint64_t>(), ids.as<uint32_t>(), 2 * NU, selfc.as<uint8_t>(), lcnt.as<uint64_t>(),
-                               (const uint64_t *)nullptr, (uint32_t *)nullptr, nv.as<unsigned long long>());
+                               (const uint64_t *)nullptr, (uint64_t *)nullptr, nv.as<unsigned long long>());
             check_launch("k_links<count>");
             const uint64_t NL = exclusive_scan_u64(ctx, lcnt.as<uint64_t>(), lcnt.as<uint64_t>(), 2 * NU);
-            DevBuf dl(NL * 8 + 16);
+            DevBuf dl(NL * 16 + 16);
             hipLaunchKernelGGL((k_links<true>), dim3((unsigned)((2 * NU + 255) / 256)), dim3(256), 0, ctx->stream,
                                rec.as<uint64_t>(), ids.as<uint32_t>(), 2 * NU, selfc.as<uint8_t>(), (uint64_t *)nullptr,
-                               lcnt.as<uint64_t>(), dl.as<uint32_t>(), (unsigned long long *)nullptr);
+                               lcnt.as<uint64_t>(), dl.as<uint64_t>(), (unsigned long long *)nullptr);
             check_launch("k_links<write>");
             unsigned long long hv = 0;
             d2h(ctx, &hv, nv.p, 8);
@@ -593,29 +618,24 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
         T.k = k;
         T.W = (int)x->W;
         T.idx.resize(NC);
-        DevBuf cidx(NC * 4 + 16);
+        DevBuf cidx(NC * 8 + 16);
         hipLaunchKernelGGL(k_compact_candidates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                            flag.as<uint64_t>(), x->masks.as<uint8_t>(), visited.as<uint8_t>(), n,
-                           cidx.as<uint32_t>());
+                           cidx.as<uint64_t>());
         check_launch("k_compact_candidates");
-        d2h(ctx, T.idx.data(), cidx.p, NC * 4);
+        d2h_big(ctx, T.idx.data(), cidx.p, NC * 8);
         T.keys.resize(NC * T.W);
         T.masks.resize(NC);
         T.used.assign(NC, 0);
-        // gather the candidate rows (few): one small copy each would be slow for many loops, so copy
-        // the covering range when it is dense, else row by row
-        std::vector<uint64_t> allk;
-        std::vector<uint8_t> allm;
-        const uint32_t lo = T.idx.front(), hi = T.idx.back();
-        const uint64_t span = (uint64_t)hi - lo + 1;
-        allk.resize(span * T.W);
-        allm.resize(span);
-        d2h(ctx, allk.data(), x->keys.as<uint64_t>() + (uint64_t)lo * T.W, span * T.W * 8);
-        d2h(ctx, allm.data(), x->masks.as<uint8_t>() + lo, span);
-        for (uint64_t c = 0; c < NC; ++c) {
-            const uint64_t r = T.idx[c] - lo;
-            for (int w = 0; w < T.W; ++w) T.keys[c * T.W + w] = allk[r * T.W + w];
-            T.masks[c] = allm[r];
+        // gather the candidate rows on the device (they may lie anywhere in a table of billions of k-mers)
+        {
+            DevBuf gk(NC * T.W * 8 + 16), gm(NC + 16);
+            hipLaunchKernelGGL(k_gather_candidates, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, ctx->stream,
+                               x->keys.as<uint64_t>(), x->masks.as<uint8_t>(), cidx.as<uint64_t>(), NC, T.W,
+                               gk.as<uint64_t>(), gm.as<uint8_t>());
+            check_launch("k_gather_candidates");
+            d2h_big(ctx, T.keys.data(), gk.p, NC * T.W * 8);
+            d2h_big(ctx, T.masks.data(), gm.p, NC);
         }
         auto oriented_mask = [&](long pos, bool minimal) -> uint32_t {
             return minimal ? T.masks[(size_t)pos] : rev8(T.masks[(size_t)pos]);
@@ -634,7 +654,7 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
                 bool minimal;
                 const long pos = T.find(km, &minimal);
                 BBK_REQUIRE(pos >= 0, BBK_ERR_INTERNAL, "loop end k-mer missing from the candidate table");
-                recs.push_back({((uint64_t)T.idx[(size_t)pos] << 2) | ((uint64_t)(minimal ? 0 : 1) << 1) |
+                recs.push_back({(T.idx[(size_t)pos] << 2) | ((uint64_t)(minimal ? 0 : 1) << 1) |
                                     (uint64_t)is_start,
                                 (uint32_t)id});
             }
@@ -720,8 +740,8 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
                 if (!((b_start && !b_rc) || (!b_start && b_rc))) continue;  // outgoing
                 const uint32_t eb = recs[b].edge;
                 const uint32_t ob = (b_start || selfconj[eb]) ? 1u : 0u;
-                U.links.push_back((ea << 1) | oa);
-                U.links.push_back((eb << 1) | ob);
+                U.links.push_back(((uint64_t)ea << 1) | oa);
+                U.links.push_back(((uint64_t)eb << 1) | ob);
             }
         }
         p = q;
@@ -730,7 +750,8 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     U.n_links = U.links.size() / 2;
 }
 
-unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsigned k, uint64_t n, DevBuf &prefix);
+unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsigned k, uint64_t n, DevBuf &prefix,
+                            bool *wide);
 
 // One thread per unitig: roll the (k+1)-mers of the sequence, look the canonical form up in the
 // sorted (k+1)-mer count table, add the multiplicities (GraphCoverageFiller,
@@ -738,8 +759,8 @@ unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsi
 template <int W>
 __global__ __launch_bounds__(256) void k_unitig_kc(const char *__restrict__ bases, const uint64_t *__restrict__ off,
                                                   uint64_t n_unitigs, int k1, const Key<W> *__restrict__ keys,
-                                                  const uint32_t *__restrict__ counts, const uint32_t *__restrict__ pref,
-                                                  int pshift, uint64_t *__restrict__ kc, uint32_t *__restrict__ err) {
+                                                  const uint32_t *__restrict__ counts, PrefixTable P,
+                                                  uint64_t *__restrict__ kc, uint32_t *__restrict__ err) {
     const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n_unitigs) return;
     const char *s = bases + off[u];
@@ -756,8 +777,8 @@ __global__ __launch_bounds__(256) void k_unitig_kc(const char *__restrict__ base
             const Key<W> rc = kmer_rc<W>(cur, k1);
             const bool minimal = !kmer_less_nucl<W>(rc, cur);
             const Key<W> q = key_select<W>(minimal, cur, rc);
-            const uint32_t j = find_kmer<W>(keys, pref, pshift, q);
-            if (j == 0xFFFFFFFFu) atomicOr(err, 4u);
+            const uint64_t j = table_find<W>(keys, P, q);
+            if (j == kNotFound) atomicOr(err, 4u);
             else sum += counts[j];
         }
     }
@@ -766,12 +787,12 @@ __global__ __launch_bounds__(256) void k_unitig_kc(const char *__restrict__ base
 
 template <int W>
 static void run_kc(bbk_ctx *ctx, const char *d_bases, const uint64_t *d_off, uint64_t nu, unsigned k1,
-                   const bbk_kmerset *set, const DevBuf &pref, unsigned pbits, uint64_t *d_kc, uint32_t *d_err) {
+                   const bbk_kmerset *set, const DevBuf &pref, unsigned pbits, bool wide, uint64_t *d_kc, uint32_t *d_err) {
     const int w0bits = (W == 1) ? (int)(2 * k1) : 64;
     KernelTimer t(ctx, "coverage", 0);
     hipLaunchKernelGGL(k_unitig_kc<W>, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, d_off, nu,
-                       (int)k1, set->keys.as<Key<W>>(), set->counts.as<uint32_t>(), pref.as<uint32_t>(),
-                       w0bits - (int)pbits, d_kc, d_err);
+                       (int)k1, set->keys.as<Key<W>>(), set->counts.as<uint32_t>(),
+                       PrefixTable{pref.p, w0bits - (int)pbits, wide ? 1 : 0}, d_kc, d_err);
     check_launch("k_unitig_kc");
 }
 
@@ -787,23 +808,22 @@ static void coverage_from_counts(bbk_ctx *ctx, bbk_unitigs *u, const bbk_kmerset
     BBK_REQUIRE(set->k == k1 && set->has_counts && set->sorted && !set->ref_order && (set->flags & BBK_CANONICAL),
                 BBK_ERR_ARG, "coverage needs the ascending canonical %u-mer set with counts "
                 "(BBK_CANONICAL | BBK_WITH_COUNTS at k + 1)", k1);
-    BBK_REQUIRE(set->n < (1ull << 32), BBK_ERR_ARG, "coverage table of %llu (k+1)-mers exceeds the 32-bit lookup index",
-                (unsigned long long)set->n);
     ensure_host(ctx, u);
     u->kc.assign(u->n, 0);
     u->has_cov = true;
     if (u->n == 0) return;
     DevBuf pref;
-    const unsigned pbits = build_prefix_index(ctx, set->keys.as<uint64_t>(), set->W, k1, set->n, pref);
+    bool wide = false;
+    const unsigned pbits = build_prefix_index(ctx, set->keys.as<uint64_t>(), set->W, k1, set->n, pref, &wide);
     DevBuf d_bases(u->bases.size() + 16), d_off((u->n + 1) * 8), d_kc(u->n * 8), d_err(16);
     BBK_HIP(hipMemcpyAsync(d_bases.p, u->bases.data(), u->bases.size(), hipMemcpyHostToDevice, ctx->stream));
     BBK_HIP(hipMemcpyAsync(d_off.p, u->offsets.data(), (u->n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     BBK_HIP(hipMemsetAsync(d_err.p, 0, 16, ctx->stream));
     switch (set->W) {
-        case 1: run_kc<1>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
-        case 2: run_kc<2>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
-        case 3: run_kc<3>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
-        case 4: run_kc<4>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
+        case 1: run_kc<1>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, wide, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
+        case 2: run_kc<2>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, wide, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
+        case 3: run_kc<3>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, wide, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
+        case 4: run_kc<4>(ctx, d_bases.as<char>(), d_off.as<uint64_t>(), u->n, k1, set, pref, pbits, wide, d_kc.as<uint64_t>(), d_err.as<uint32_t>()); break;
         default: BBK_REQUIRE(false, BBK_ERR_ARG, "unsupported key width %u", set->W);
     }
     uint32_t herr = 0;
@@ -841,12 +861,62 @@ int bbk_unitigs_export_kc(bbk_ctx *ctx, const bbk_unitigs *u, uint64_t *h_kc) {
     });
 }
 
+int bbk_unitigs_to_reads(bbk_ctx *ctx, const bbk_unitigs *u, bbk_reads **out) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && u && out, BBK_ERR_ARG, "bbk_unitigs_to_reads: NULL argument");
+        BBK_HIP(hipSetDevice(ctx->device));
+        const uint64_t nu = u->n;
+        // the device-resident result is used in place; a result that lives on the host (loops were appended) is uploaded
+        DevBuf up_bases, up_off;
+        const char *d_bases = u->d_bases.as<char>();
+        const uint64_t *d_uoff = u->d_uoff.as<uint64_t>();
+        uint64_t total = u->total_bases;
+        if (u->host_valid) {
+            total = u->bases.size();
+            up_bases.alloc(total + 16);
+            up_off.alloc((nu + 1) * 8);
+            if (total) BBK_HIP(hipMemcpyAsync(up_bases.p, u->bases.data(), total, hipMemcpyHostToDevice, ctx->stream));
+            BBK_HIP(hipMemcpyAsync(up_off.p, u->offsets.data(), (nu + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+            d_bases = up_bases.as<char>();
+            d_uoff = up_off.as<uint64_t>();
+        }
+        auto rd = std::make_unique<bbk_reads>();
+        rd->ctx = ctx;
+        rd->n = nu;
+        rd->bases = total;
+        rd->own_woff.alloc((nu + 1) * sizeof(uint64_t));
+        rd->own_len.alloc((nu + 1) * sizeof(uint32_t));
+        uint64_t nwords = 0;
+        if (nu) {
+            DevBuf err(16);
+            BBK_HIP(hipMemsetAsync(err.p, 0, 16, ctx->stream));
+            hipLaunchKernelGGL(k_unitig_words, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, ctx->stream, d_uoff, nu,
+                               rd->own_woff.as<uint64_t>(), rd->own_len.as<uint32_t>(), err.as<uint32_t>());
+            check_launch("k_unitig_words");
+            nwords = exclusive_scan_u64(ctx, rd->own_woff.as<uint64_t>(), rd->own_woff.as<uint64_t>(), nu);
+            uint32_t herr = 0;
+            d2h(ctx, &herr, err.p, 4);
+            BBK_REQUIRE(herr == 0, BBK_ERR_ARG, "bbk_unitigs_to_reads: a unitig is longer than 2^32 - 1 bases");
+        }
+        BBK_HIP(hipMemcpyAsync(rd->own_woff.as<uint64_t>() + nu, &nwords, 8, hipMemcpyHostToDevice, ctx->stream));
+        rd->n_words = nwords;
+        rd->own_words.alloc((nwords + 1) * sizeof(uint64_t));
+        if (nu) {
+            hipLaunchKernelGGL(k_pack_unitigs, dim3((unsigned)((nu * 64 + 255) / 256)), dim3(256), 0, ctx->stream, d_bases,
+                               d_uoff, rd->own_woff.as<uint64_t>(), nu, rd->own_words.as<uint64_t>());
+            check_launch("k_pack_unitigs");
+        }
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        rd->d_words = rd->own_words.as<uint64_t>();
+        rd->d_woff = rd->own_woff.as<uint64_t>();
+        rd->d_len = rd->own_len.as<uint32_t>();
+        *out = rd.release();
+    });
+}
+
 int bbk_unitigs_build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs **out) {
     return guarded([&] {
         BBK_REQUIRE(ctx && x && out, BBK_ERR_ARG, "bbk_unitigs_build: NULL argument");
-        BBK_REQUIRE(x->n < (1ull << 32), BBK_ERR_ARG,
-                    "bbk_unitigs_build: %llu k-mers; the graph stage indexes k-mers, start edges and link records with "
-                    "32 bits (shard the extension index)", (unsigned long long)x->n);
         BBK_HIP(hipSetDevice(ctx->device));
         auto u = std::make_unique<bbk_unitigs>();
         build(ctx, x, *u);
@@ -876,10 +946,10 @@ int bbk_unitigs_export_links(bbk_ctx *ctx, const bbk_unitigs *u, uint32_t *h_lin
         BBK_REQUIRE(ctx && u && (u->n_links == 0 || h_links), BBK_ERR_ARG, "bbk_unitigs_export_links: NULL argument");
         ensure_host(ctx, u);
         for (uint64_t l = 0; l < u->n_links; ++l) {
-            h_links[4 * l] = u->links[2 * l] >> 1;
-            h_links[4 * l + 1] = u->links[2 * l] & 1u;
-            h_links[4 * l + 2] = u->links[2 * l + 1] >> 1;
-            h_links[4 * l + 3] = u->links[2 * l + 1] & 1u;
+            h_links[4 * l] = (uint32_t)(u->links[2 * l] >> 1);  // edge ids are below 2^31 (build)
+            h_links[4 * l + 1] = (uint32_t)(u->links[2 * l] & 1u);
+            h_links[4 * l + 2] = (uint32_t)(u->links[2 * l + 1] >> 1);
+            h_links[4 * l + 3] = (uint32_t)(u->links[2 * l + 1] & 1u);
         }
     });
 }
@@ -912,7 +982,7 @@ static void write_gfa_device(bbk_ctx *ctx, const bbk_unitigs *u, const char *pat
     for (unsigned v = u->k; v >= 10; v /= 10) ++klen;
     if (nl) {
         hipLaunchKernelGGL(k_gfa_l_len, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream,
-                           u->d_links.as<uint32_t>(), nl, klen, lpos.as<uint64_t>());
+                           u->d_links.as<uint64_t>(), nl, klen, lpos.as<uint64_t>());
         check_launch("k_gfa_l_len");
         lbytes = exclusive_scan_u64(ctx, lpos.as<uint64_t>(), lpos.as<uint64_t>(), nl);
     }
@@ -928,7 +998,7 @@ static void write_gfa_device(bbk_ctx *ctx, const bbk_unitigs *u, const char *pat
         }
         if (nl) {
             hipLaunchKernelGGL(k_gfa_l_write, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream,
-                               u->d_links.as<uint32_t>(), lpos.as<uint64_t>(), nl, (uint32_t)u->k, klen,
+                               u->d_links.as<uint64_t>(), lpos.as<uint64_t>(), nl, (uint32_t)u->k, klen,
                                text.as<char>() + sbytes);
             check_launch("k_gfa_l_write");
         }
@@ -1063,21 +1133,20 @@ int bbk_unitigs_write_gfa(bbk_ctx *ctx, const bbk_unitigs *u, const char *path) 
         lpos[0] = 0;
 #pragma omp parallel for schedule(static) num_threads(host_threads())
         for (uint64_t l = 0; l < nl; ++l)
-            lpos[l + 1] = 2 + dec_len(3 + 2 * (uint64_t)(u->links[2 * l] >> 1)) + 3 +
-                          dec_len(3 + 2 * (uint64_t)(u->links[2 * l + 1] >> 1)) + 3 + kl + 2;
+            lpos[l + 1] = 2 + dec_len(3 + 2 * (u->links[2 * l] >> 1)) + 3 + dec_len(3 + 2 * (u->links[2 * l + 1] >> 1)) + 3 + kl + 2;
         prefix_sum(lpos, nl);
         raw_vector<char> lbuf(lpos[nl]);
 #pragma omp parallel for schedule(static) num_threads(host_threads())
         for (uint64_t l = 0; l < nl; ++l) {
             char *d = lbuf.data() + lpos[l];
-            const uint32_t a = u->links[2 * l], b2 = u->links[2 * l + 1];
+            const uint64_t a = u->links[2 * l], b2 = u->links[2 * l + 1];
             *d++ = 'L';
             *d++ = '\t';
-            d += fmt_u64(d, 3 + 2 * (uint64_t)(a >> 1));
+            d += fmt_u64(d, 3 + 2 * (a >> 1));
             *d++ = '\t';
             *d++ = (a & 1u) ? '+' : '-';
             *d++ = '\t';
-            d += fmt_u64(d, 3 + 2 * (uint64_t)(b2 >> 1));
+            d += fmt_u64(d, 3 + 2 * (b2 >> 1));
             *d++ = '\t';
             *d++ = (b2 & 1u) ? '+' : '-';
             *d++ = '\t';
@@ -1119,24 +1188,24 @@ int bbk_unitigs_write_fastg(bbk_ctx *ctx, const bbk_unitigs *u, const char *path
             }
             selfconj[i] = sc;
         }
-        auto flip = [&](uint32_t t) { return selfconj[t >> 1] ? t : (t ^ 1u); };
+        auto flip = [&](uint64_t t) { return selfconj[t >> 1] ? t : (t ^ 1ull); };
         // adjacency of oriented edges: a stored link x -> y also means rc(y) -> rc(x)
-        std::vector<std::pair<uint32_t, uint32_t>> adj;
+        std::vector<std::pair<uint64_t, uint64_t>> adj;
         adj.reserve(2 * u->n_links);
         for (uint64_t l = 0; l < u->n_links; ++l) {
-            const uint32_t x = u->links[2 * l], y = u->links[2 * l + 1];
+            const uint64_t x = u->links[2 * l], y = u->links[2 * l + 1];
             adj.emplace_back(x, y);
             adj.emplace_back(flip(y), flip(x));
         }
         std::sort(adj.begin(), adj.end());
         adj.erase(std::unique(adj.begin(), adj.end()), adj.end());
-        auto name = [&](uint32_t t) {
+        auto name = [&](uint64_t t) {
             const uint64_t i = t >> 1;
             const uint64_t len = u->offsets[i + 1] - u->offsets[i];
             const double cov = u->has_cov ? (double)u->kc[i] / (double)(len - u->k) : 0.0;
             std::string s = "EDGE_" + std::to_string(3 + 2 * i) + "_length_" + std::to_string(len) + "_cov_" +
                             std::to_string(cov);
-            if (!(t & 1u)) s += "'";
+            if (!(t & 1ull)) s += "'";
             return s;
         };
         FILE *f = fopen(path, "wb");
@@ -1147,9 +1216,9 @@ int bbk_unitigs_write_fastg(bbk_ctx *ctx, const bbk_unitigs *u, const char *path
         for (uint64_t i = 0; i < n && ok; ++i) {
             for (int o = 1; o >= 0 && ok; --o) {
                 if (o == 0 && selfconj[i]) continue;
-                const uint32_t t = (uint32_t)(i << 1) | (uint32_t)o;
+                const uint64_t t = (i << 1) | (uint64_t)o;
                 // successors of t: adj is sorted by (from, to); orientation '-' (0) sorts before '+' (1)
-                auto lo = std::lower_bound(adj.begin(), adj.end(), std::make_pair(t, 0u));
+                auto lo = std::lower_bound(adj.begin(), adj.end(), std::make_pair(t, (uint64_t)0));
                 std::vector<std::string> next;
                 for (auto it = lo; it != adj.end() && it->first == t; ++it) next.push_back(name(it->second));
                 std::sort(next.begin(), next.end());

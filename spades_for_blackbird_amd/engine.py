@@ -23,7 +23,7 @@ SYMBOLS = [
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_clip_tips", "bbk_extindex_free",
-    "bbk_unitigs_build", "bbk_unitigs_add_coverage", "bbk_unitigs_add_coverage_counts", "bbk_unitigs_export_kc", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
+    "bbk_unitigs_build", "bbk_unitigs_to_reads", "bbk_unitigs_add_coverage", "bbk_unitigs_add_coverage_counts", "bbk_unitigs_export_kc", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
     "bbk_unitigs_vertices", "bbk_unitigs_links", "bbk_unitigs_export", "bbk_unitigs_export_links",
     "bbk_unitigs_write_gfa", "bbk_unitigs_write_fasta", "bbk_unitigs_write_fastg", "bbk_unitigs_write_spades", "bbk_unitigs_free",
 ]
@@ -143,6 +143,7 @@ def load_library():
         L.bbk_extindex_free.argtypes = [vp]
     if hasattr(L, "bbk_unitigs_build"):
         L.bbk_unitigs_build.argtypes = [vp, vp, C.POINTER(vp)]
+        L.bbk_unitigs_to_reads.argtypes = [vp, vp, C.POINTER(vp)]
         for f in ("count", "loops", "total_bases", "vertices", "links"):
             getattr(L, "bbk_unitigs_" + f).restype = u64
             getattr(L, "bbk_unitigs_" + f).argtypes = [vp]
@@ -570,6 +571,13 @@ class Unitigs(_Handle):
         _check(self._L.bbk_unitigs_export(self.ctx._h, self._h, _ptr(buf), _ptr(offs)))
         b = buf.tobytes()
         return [b[int(offs[i]):int(offs[i + 1])].decode() for i in range(n)]
+
+    def to_reads(self):
+        """the condensed edges as a device-resident read set (contigs of this K as input of the next,
+        stages/construction.cpp:117-119,228-236)"""
+        h = C.c_void_p()
+        _check(self._L.bbk_unitigs_to_reads(self.ctx._h, self._h, C.byref(h)))
+        return Reads(self.ctx, h)
 
     def add_coverage(self, reads):
         """gbuilder -c: KC / DP of every condensed edge from the reads."""

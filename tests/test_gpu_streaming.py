@@ -199,12 +199,12 @@ def test_superk_equals_kmer_path_at_size(k, meta, monkeypatch):
     ctx.profile(True)
     ctx.profile_reset()
     a, ak, am = run()
-    assert ctx.profile_get("sk_dedup")["launches"] >= 3, "the super-k-mer path did not run"
+    assert ctx.profile_get("k_sk_dedup")["launches"] >= 3, "the super-k-mer path did not run"
     assert ctx.profile_get("stat_superk_declined")["launches"] == 0
     monkeypatch.setenv("BBK_NO_SUPERK", "1")
     ctx.profile_reset()
     b, bk, bm = run()
-    assert ctx.profile_get("sk_dedup")["launches"] == 0
+    assert ctx.profile_get("k_sk_dedup")["launches"] == 0
     for (k1, c1), (k2, c2) in zip(a, b):
         assert k1.shape == k2.shape and bool(torch.equal(k1, k2)) and bool(torch.equal(c1, c2))
         assert int(c1.sum(dtype=torch.int64).item()) == n_reads * (L - k + 1)

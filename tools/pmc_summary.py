@@ -16,23 +16,26 @@ import json
 import re
 import sys
 
-FAMILY = [  # k_part_reads<W, HAS_VAL, HIST_ONLY>, k_part<W, HAS_VAL, HIST_ONLY, LVL1>
-    (r"k_sk_part1", "sk_part1"),
-    (r"k_sk_part2<\d, true>", "sk_hist2"),
-    (r"k_sk_part2<\d, false>", "sk_part2"),
-    (r"k_sk_dedup<.*SkdB>", "sk_dedup2"),
-    (r"k_sk_dedup", "sk_dedup"),
-    (r"k_part_reads_narrow", "part_scatter1_reads"),
-    (r"k_part_narrow2", "part_scatter2"),
-    (r"k_bucket_hash32", "lds_dedup"),
-    (r"k_part_reads<\d, (true|false), false>", "part_scatter1_reads"),
-    (r"k_part_reads<\d, (true|false), true>", "part_hist1_reads"),
-    (r"k_part<\d, (true|false), false, true>", "part_scatter1_keys"),
-    (r"k_part<\d, (true|false), false, false>", "part_scatter2"),
-    (r"k_part<\d, (true|false), true, true>", "part_hist1_keys"),
-    (r"k_part<\d, (true|false), true, false>", "part_hist2"),
-    (r"k_bucket_hash", "lds_dedup"),
-    (r"k_bucket(_dist)?<", "lds_sort"),
+FAMILY = [  # rocprof kernel symbol -> the name bbk_ctx_profile_get / bench.py use for the same kernel
+    # k_part_reads<W, HAS_VAL, HIST_ONLY>, k_part<W, HAS_VAL, HIST_ONLY, LVL1> (LVL1 also serves the level-0 pass)
+    (r"k_sk_part1", "k_sk_part1"),
+    (r"k_sk_part2<\d, true>", "k_sk_part2_hist"),
+    (r"k_sk_part2<\d, false>", "k_sk_part2"),
+    (r"k_sk_dedup<.*SkdB>", "k_sk_dedup_B"),
+    (r"k_sk_dedup", "k_sk_dedup"),
+    (r"k_part_reads_narrow", "k_part_reads_narrow"),
+    (r"k_part_narrow2", "k_part_narrow2"),
+    (r"k_bucket_hash32", "k_bucket_hash32"),
+    (r"k_part_reads<\d, (true|false), false>", "k_part_reads"),
+    (r"k_part_reads<\d, (true|false), true>", "k_part_reads_hist"),
+    (r"k_part<\d, (true|false), false, true>", "k_part_l1"),
+    (r"k_part<\d, (true|false), false, false>", "k_part_l2"),
+    (r"k_part<\d, (true|false), true, true>", "k_part_hist1"),
+    (r"k_part<\d, (true|false), true, false>", "k_part_hist2"),
+    (r"k_bucket_hashidx", "k_bucket_hashidx"),
+    (r"k_bucket_hash", "k_bucket_hash"),
+    (r"k_bucket_dist<", "k_bucket_dist"),
+    (r"k_bucket<", "k_bucket"),
     (r"k_compact", "compact"),
     (r"k_scatter<", "scatter"),
     (r"k_hist<", "hist"),
