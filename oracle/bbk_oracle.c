@@ -142,6 +142,51 @@ static const uint64_t kSec48 = 0x8e2443f7744608b8ULL;  /* secret+48 */
 static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 static inline uint64_t bswap64(uint64_t x) { return __builtin_bswap64(x); }
 
+/* ---- Sequence views (common/sequence/sequence.hpp) ------------------------------------------------------- */
+int orc_complement(int code) { return 3 - code; }            /* nucl.hpp:27-34 */
+char orc_nucl(int code) { return "ACGT"[code & 3]; }         /* nucl.hpp:105-112 */
+orc_seq orc_seq_make(const char *acgt) {
+    orc_seq s = {acgt, 0, strlen(acgt), 0};
+    return s;
+}
+int orc_seq_at(const orc_seq *s, size_t i) { /* sequence.hpp:311-319 */
+    if (s->rtl) return orc_complement(orc_dignucl(s->data[s->from + s->size - 1 - i]));
+    return orc_dignucl(s->data[s->from + i]);
+}
+orc_seq orc_seq_rc(const orc_seq *s) { /* operator! :232-234 */
+    orc_seq r = *s;
+    r.rtl = !s->rtl;
+    return r;
+}
+orc_seq orc_seq_subseq(const orc_seq *s, size_t from, size_t to) { /* :324-333 */
+    orc_seq r = *s;
+    r.size = to - from;
+    r.from = s->rtl ? s->from + s->size - to : s->from + from;
+    return r;
+}
+int orc_seq_less(const orc_seq *a, const orc_seq *b) { /* :222-230 */
+    const size_t n = a->size < b->size ? a->size : b->size;
+    for (size_t i = 0; i < n; ++i) {
+        const int x = orc_seq_at(a, i), y = orc_seq_at(b, i);
+        if (x != y) return x < y;
+    }
+    return a->size < b->size;
+}
+int orc_seq_eq(const orc_seq *a, const orc_seq *b) {
+    if (a->size != b->size) return 0;
+    for (size_t i = 0; i < a->size; ++i)
+        if (orc_seq_at(a, i) != orc_seq_at(b, i)) return 0;
+    return 1;
+}
+void orc_seq_str(const orc_seq *s, char *out) { /* :377-383 */
+    for (size_t i = 0; i < s->size; ++i) out[i] = orc_nucl(orc_seq_at(s, i));
+    out[s->size] = 0;
+}
+void orc_seq_concat(const orc_seq *a, const orc_seq *b, char *out) { /* :361-362 */
+    orc_seq_str(a, out);
+    orc_seq_str(b, out + a->size);
+}
+
 uint64_t orc_mulhi64(uint64_t x, uint64_t y) { /* lemiere_mod_reduce.hpp:17-35 */
     return (uint64_t)(((__uint128_t)x * (__uint128_t)y) >> 64);
 }

@@ -53,6 +53,25 @@ int orc_kmer_is_minimal(const orc_kmer *x, int k);      /* rtseq.hpp:407-415 */
 int orc_kmer_less_nucl(const orc_kmer *a, const orc_kmer *b, int k); /* rtseq.hpp:732-741 operator< */
 int orc_kmer_cmp_words(const uint64_t *a, const uint64_t *b, int nw); /* adt/array_vector.hpp:114-123 */
 
+/* ---- Sequence (common/sequence/sequence.hpp): a view (from, size, rtl) over shared 2-bit storage; the unitig
+ *      orientation rule `if (s < !s) continue` (debruijn_graph_constructor.hpp:279) is stated in its operators.
+ *      `data` stands for the storage: ACGT text of the underlying forward sequence. ---- */
+typedef struct {
+    const char *data;
+    size_t from, size;
+    int rtl; /* read right-to-left, complemented */
+} orc_seq;
+orc_seq orc_seq_make(const char *acgt);                         /* sequence.hpp:71-122 */
+int orc_seq_at(const orc_seq *s, size_t i);                     /* operator[] :311-319: rtl -> complement(data[from+size-1-i]) */
+orc_seq orc_seq_rc(const orc_seq *s);                           /* operator! :232-234: same storage, rtl flipped */
+orc_seq orc_seq_subseq(const orc_seq *s, size_t from, size_t to); /* Subseq :324-333 */
+int orc_seq_less(const orc_seq *a, const orc_seq *b);           /* operator< :222-230: base-lexicographic, shorter prefix first */
+int orc_seq_eq(const orc_seq *a, const orc_seq *b);             /* operator== */
+void orc_seq_str(const orc_seq *s, char *out);                  /* str() :377-383; out holds size + 1 bytes */
+void orc_seq_concat(const orc_seq *a, const orc_seq *b, char *out); /* operator+ :361-362: Sequence(str() + s.str()) */
+int orc_complement(int code);                                   /* nucl.hpp:27-34 */
+char orc_nucl(int code);                                        /* nucl.hpp:105-112 */
+
 /* ---- bucket policy ---- */
 uint64_t orc_xxh3_64(const uint64_t *words, int nwords); /* ext/include/xxh/xxhash.h:2781-2822,2850-2908, seed 0 */
 uint64_t orc_mulhi64(uint64_t x, uint64_t y);            /* adt/lemiere_mod_reduce.hpp:17-35 */

@@ -124,6 +124,7 @@ std::unique_ptr<Arena> arena_reserve() {
 void arena_shrink(Arena &A) {
     const double t0 = wall_s();
     size_t at = 0;
+    bool unmapped = false;
     while (!A.chunks.empty() && A.shrink_one(kArenaChunk, &at)) {
         const hipError_t eu = hipMemUnmap(A.base + at, kArenaChunk);
         if (eu != hipSuccess) {  // still mapped, but no longer in the index: the chunk is lost to this arena, not reused
@@ -138,6 +139,20 @@ void arena_shrink(Arena &A) {
         }
         A.chunks.pop_back();
         ++pool().frees;
+        unmapped = true;
+    }
+    if (unmapped) {
+        // an ordinary allocation freed after the unmaps makes the driver invalidate the device's address translations
+        // (probe modes flush_before / flush_after: a re-mapped range is coherent again after this).  The arena does not
+        // depend on it -- it never maps at a retired address -- but whoever gets the freed memory next should not meet
+        // stale translations of ours either.
+        void *o = nullptr;
+        if (hipMalloc(&o, 64ull << 20) == hipSuccess) {
+            (void)hipMemset(o, 0, 64ull << 20);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(o);
+        }
+        (void)hipGetLastError();
     }
     pool().free_s += wall_s() - t0;
 }

@@ -439,3 +439,71 @@ def test_spades_binary_graph(ctx, k, seed, tmp_path):
         e, c = struct.unpack_from("<QI", cv, 12 * i)
         assert e == 3 + 2 * i and c == kc[i]
     assert struct.unpack_from("<Q", cv, 12 * len(seqs))[0] == 0
+
+
+# ---- 64-bit graph stage ------------------------------------------------------------------------------------------
+# KMerIndex::seq_idx is a size_t (utils/kmer_mph/kmer_index.hpp:85-90) and LinkRecord keys are 64-bit
+# (debruijn_graph_constructor.hpp:400-430).  Here the prefix table takes 64-bit entries from 2^32-2 k-mers on;
+# BBK_WIDE_INDEX=1 forces them, so that the same code path the >2^32 test (tests/test_gpu_graph64.py) runs is compared
+# with the oracle bit for bit at sizes the oracle can do.
+@pytest.fixture()
+def wide_index(monkeypatch):
+    monkeypatch.setenv("BBK_WIDE_INDEX", "1")
+
+
+@pytest.mark.parametrize("k", [5, 21, 33, 65])
+def test_wide_index_gfa_vs_oracle(ctx, wide_index, tmp_path, k):
+    reads = synth_reads(400, read_len=130, genome_len=3000, sub_rate=0.01, seed=900 + k, n_rate=0.002)
+    reads += ["ACGGTCATTGCAGGATCCTA" * 2, "CTTGCTGTGTCCACCCCATCGGAC" * 2]  # a self-conjugate edge, a perfect loop at k = 5
+    txt, u = gpu_gfa(ctx, reads, k, tmp_path)
+    exp_txt = O.ExtIndex(reads, k, 1).unitigs().gfa()[0]
+    assert gfa_canon.canon_md5(txt, k) == gfa_canon.canon_md5(exp_txt, k)
+    # coverage through the wide lookup of the (k+1)-mer table
+    u.add_coverage(ctx.reads_from_ascii(reads))
+    p = str(tmp_path / "c.gfa")
+    u.write_gfa(p)
+    exp_cov = O.ExtIndex(reads, k, 1).unitigs().gfa(with_cov=True)[0]
+    assert gfa_canon.canon_md5(open(p).read(), k, with_kc=True) == gfa_canon.canon_md5(exp_cov, k, with_kc=True)
+
+
+def test_wide_index_tip_clipping_same_as_narrow(ctx, monkeypatch):
+    reads = synth_reads(600, read_len=120, genome_len=4000, sub_rate=0.01, seed=77)
+    r = ctx.reads_from_ascii(reads)
+    x0 = ctx.extindex(r, 21)
+    rm0 = x0.clip_tips(42)
+    k0, m0 = x0.export()
+    monkeypatch.setenv("BBK_WIDE_INDEX", "1")
+    x1 = ctx.extindex(r, 21)
+    rm1 = x1.clip_tips(42)
+    k1, m1 = x1.export()
+    assert rm0 == rm1 and np.array_equal(k0, k1) and np.array_equal(m0, m1)
+
+
+def test_unitigs_to_reads_and_graph_invariants(ctx, tmp_path):
+    """The size-independent properties tests/test_gpu_graph64.py relies on, checked where the oracle can confirm them:
+    the canonical (k+1)-mers spelled by the segments are pairwise distinct and are exactly the (k+1)-mers of the reads
+    (SURVEY 8a "universal invariant"); vertices = junction k-mers with an edge; links = sum over them of in x out."""
+    k = 21
+    reads = synth_reads(3000, read_len=150, genome_len=9000, sub_rate=0.005, seed=5)
+    r = ctx.reads_from_ascii(reads)
+    x = ctx.extindex(r, k)
+    u = ctx.unitigs(x)
+    assert u.n_loops == 0
+    ur = u.to_reads()
+    assert ur.to_list() == u.sequences()
+    e_reads = ctx.count(r, k + 1, B.CANONICAL | B.WITH_COUNTS)
+    e_unitigs = ctx.count(ur, k + 1, B.CANONICAL | B.WITH_COUNTS)
+    seqs = u.sequences()
+    assert len(e_unitigs) == sum(len(s) - k for s in seqs) == len(e_reads)
+    ku, cu = e_unitigs.export(with_counts=True)
+    kr, _ = e_reads.export(with_counts=True)
+    assert np.array_equal(ku, kr) and int(cu.max()) == 1
+    _, masks = x.export()
+    pop = np.array([bin(i).count("1") for i in range(16)])
+    outs, ins = pop[masks & 15], pop[masks >> 4]
+    junction = (outs != 1) | (ins != 1)
+    assert u.n_vertices == int(junction.sum())
+    assert u.n_links == int((outs[junction] * ins[junction]).sum())
+    exp = O.ExtIndex(reads, k, 1).unitigs()
+    _, nv, nl = exp.gfa()
+    assert (len(u), u.n_vertices, u.n_links) == (exp.n, nv, nl)

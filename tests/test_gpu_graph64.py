@@ -1,0 +1,162 @@
+"""GPU: the graph stage above 2^32 k-mers on ONE MI355X -- what BASELINE configs[3] (1 B reads, ~15 G k-mers over eight
+GPUs) needs from every stage: extension index -> unitigs -> links -> GFA with 64-bit k-mer indices throughout
+(KMerIndex::seq_idx is a size_t, utils/kmer_mph/kmer_index.hpp:85-90; LinkRecord keys are 64-bit,
+assembly_graph/construction/debruijn_graph_constructor.hpp:400-430).
+
+44 M x 150 bp reads at ~0.4x coverage of a 16 Gbp uniform genome, k = 21, pushed in blocks: ~4.5 G distinct canonical
+21-mers (> 2^32).  No oracle reaches this size; checked through the size-independent properties of SURVEY 8a, every
+one of which tests/test_gpu_graph.py::test_unitigs_to_reads_and_graph_invariants confirms against the oracle at a size
+the oracle can do:
+  * |index| > 2^32; every k-mer has an extension bit; the bits add up to 2 |E| minus the palindromic (k+1)-mers;
+  * sum over segments of (len - k) = |E| = number of distinct canonical (k+1)-mers of the reads;
+  * the canonical (k+1)-mers spelled by the segments are pairwise distinct (recounted with the engine from the segments
+    fed back as reads: as many distinct as positions) and, pushed together with the reads' own, add nothing new
+    (set equality);
+  * vertices = junction k-mers that have an edge; links = sum over them of in-degree x out-degree (from the masks);
+  * every walk finds every k-mer it steps on by binary search in the table (a table out of order fails the build);
+  * the GFA file has one S line per segment and one L line per link, nothing else, and holds at least the S lines' bytes.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+R, L, K, G = 44_000_000, 150, 21, 16_000_000_000
+BLOCKS = 4
+
+
+def _graph64():
+    import torch
+    import spades_for_blackbird_amd as B
+    free, total = torch.cuda.mem_get_info()
+    if total < 250e9:
+        print("GRAPH64-SKIP: needs the 288 GB of an MI355X")
+        return
+    import time
+    t00 = time.time()
+
+    def lap(what):
+        print("[graph64] %-34s %.1f s" % (what, time.time() - t00), flush=True)
+    ctx = B.Context(0)
+    per = R // BLOCKS
+    blocks = [ctx.reads_synth(per, read_len=L, genome_len=G, seed_genome=7, seed_reads=100 + b) for b in range(BLOCKS)]
+    # ---- extension index, streamed (DeBruijnExtensionIndexBuilder over bounded buffers) ---------------------------
+    xb = ctx.extbuilder(K)
+    for r in blocks:
+        xb.push(r)
+    x = xb.finish()
+    n = len(x)
+    lap("extension index: %d k-mers" % n)
+    assert n > (1 << 32), n
+    # ---- |E| = distinct canonical (k+1)-mers of the reads (streamed count) ------------------------------------------
+    cb = ctx.counter(K + 1, B.CANONICAL | B.UNSORTED)
+    for r in blocks:
+        cb.push(r)
+    e = cb.finish()
+    n_e = len(e)
+    e.free()
+    lap("|E| = %d distinct canonical %d-mers" % (n_e, K + 1))
+    assert n_e > (1 << 32) - (1 << 28)
+    # ---- masks: every k-mer has a bit; junction statistics for the vertex / link check ---------------------------
+    xm = torch.empty(n, dtype=torch.uint8, device="cuda")
+    x._L.bbk_extindex_export(ctx._h, x._h, None, B.engine._ptr(xm))
+    pop = torch.tensor([bin(i).count("1") for i in range(16)], dtype=torch.int64, device="cuda")
+    n_junction = links_expected = bits = 0
+    zero_masks = 0
+    for a0 in range(0, n, 1 << 28):
+        m = xm[a0:a0 + (1 << 28)]
+        outs, ins = pop[(m & 15).long()], pop[(m >> 4).long()]
+        j = (outs != 1) | (ins != 1)
+        n_junction += int(j.sum().item())
+        links_expected += int((outs * ins)[j].sum().item())
+        bits += int(outs.sum().item()) + int(ins.sum().item())
+        zero_masks += int((m == 0).sum().item())
+        del m, outs, ins, j
+    del xm
+    torch.cuda.empty_cache()
+    assert zero_masks == 0
+    # every distinct canonical (k+1)-mer sets one out bit (on its prefix k-mer) and one in bit (on its suffix k-mer,
+    # kmer_extension_index_builder.hpp:44-59); a (k+1)-mer that is its own reverse complement sets the same bit twice:
+    # a uniform 22-mer is one with probability 4^-11, i.e. ~n_e * 2.4e-7 of them
+    palindromes = 2 * n_e - bits
+    assert 0 <= palindromes <= 3 * n_e * 4.0 ** -((K + 1) // 2) + 100, (bits, n_e)
+    lap("masks: %d junction k-mers" % n_junction)
+    # ---- unitigs + links --------------------------------------------------------------------------------------------
+    u = ctx.unitigs(x)
+    nu, nb = len(u), u.total_bases
+    lap("unitigs: %d segments, %d bases, %d vertices, %d links" % (nu, nb, u.n_vertices, u.n_links))
+    assert u.n_loops == 0
+    assert nb - K * nu == n_e, (nb, nu, n_e)            # sum (len - k) = |E|
+    assert u.n_vertices == n_junction, (u.n_vertices, n_junction)
+    assert u.n_links == links_expected, (u.n_links, links_expected)
+    x.free()
+    # ---- the segments' (k+1)-mers: pairwise distinct, and the same set as the reads' --------------------------------
+    ur = u.to_reads()
+    assert len(ur) == nu and ur.bases == nb
+    cu = ctx.count(ur, K + 1, B.CANONICAL | B.UNSORTED)
+    assert cu.instances == n_e and len(cu) == n_e, (cu.instances, len(cu), n_e)
+    cu.free()
+    lap("segments recounted: pairwise distinct")
+    cb = ctx.counter(K + 1, B.CANONICAL | B.UNSORTED)
+    cb.push(ur)
+    for r in blocks:
+        cb.push(r)
+    both = cb.finish()
+    assert len(both) == n_e, (len(both), n_e)           # union adds nothing: the two sets are equal
+    both.free()
+    ur.free()
+    lap("union with the reads' (k+1)-mers: equal sets")
+    for r in blocks:
+        r.free()
+    # ---- GFA --------------------------------------------------------------------------------------------------------
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path = os.path.join(d, "bbk_graph64_%d.gfa" % os.getpid())
+    try:
+        u.write_gfa(path)
+        size = os.path.getsize(path)
+        lap("GFA written: %d bytes" % size)
+        n_s = n_l = 0
+        first = {}
+        carry = b"\n"
+        with open(path, "rb") as f:
+            while True:
+                buf = f.read(1 << 28)
+                if not buf:
+                    break
+                a = np.frombuffer(carry[-1:] + buf, dtype=np.uint8)
+                starts = a[1:][a[:-1] == 10]                      # first byte of every line
+                n_s += int((starts == ord("S")).sum())
+                n_l += int((starts == ord("L")).sum())
+                assert int(((starts != ord("S")) & (starts != ord("L"))).sum()) == 0
+                if not first:
+                    first["head"] = buf[:200]
+                carry = buf
+        assert carry[-1:] == b"\n"
+        assert n_s == nu and n_l == u.n_links, (n_s, nu, n_l, u.n_links)
+        assert first["head"].startswith(b"S\t3\t")
+        # every S line: "S\t<id>\t<bases>\tDP:f:0\tKC:i:0\n"; ids 3 + 2 i (graph_core.hpp:228)
+        ids = 3 + 2 * np.arange(nu, dtype=np.int64)
+        id_chars = int(np.floor(np.log10(ids)).astype(np.int64).sum()) + nu
+        s_bytes = nb + id_chars + nu * (2 + 1 + 15)
+        assert size > s_bytes
+        lap("GFA checked: %d S + %d L lines" % (n_s, n_l))
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+    ctx.close()
+    print("GRAPH64-OK")
+
+
+def test_graph_above_2_32_kmers():
+    """In a process of its own: it uses most of the device."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); from tests.test_gpu_graph64 import _graph64 as f; f()" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    if "GRAPH64-SKIP" in r.stdout:
+        pytest.skip("needs the 288 GB of an MI355X")
+    assert "GRAPH64-OK" in r.stdout

@@ -259,3 +259,105 @@ def test_oracle_early_tip_clipper_semantics():
     # a bound shorter than the tip leaves it alone
     ox2 = O.ExtIndex(clean + ["".join(bad)], k, 1)
     assert ox2.clip_tips(3) == (0, 0)
+
+
+class _Seq(C.Structure):
+    _fields_ = [("data", C.c_char_p), ("from_", C.c_size_t), ("size", C.c_size_t), ("rtl", C.c_int)]
+
+
+def _seq_api():
+    L = O.lib()
+    L.orc_seq_make.restype = _Seq
+    L.orc_seq_make.argtypes = [C.c_char_p]
+    L.orc_seq_rc.restype = _Seq
+    L.orc_seq_rc.argtypes = [C.POINTER(_Seq)]
+    L.orc_seq_subseq.restype = _Seq
+    L.orc_seq_subseq.argtypes = [C.POINTER(_Seq), C.c_size_t, C.c_size_t]
+    L.orc_seq_at.argtypes = [C.POINTER(_Seq), C.c_size_t]
+    L.orc_seq_less.argtypes = [C.POINTER(_Seq), C.POINTER(_Seq)]
+    L.orc_seq_eq.argtypes = [C.POINTER(_Seq), C.POINTER(_Seq)]
+    L.orc_seq_str.argtypes = [C.POINTER(_Seq), C.c_char_p]
+    L.orc_seq_concat.argtypes = [C.POINTER(_Seq), C.POINTER(_Seq), C.c_char_p]
+    L.orc_nucl.restype = C.c_char
+    return L
+
+
+def _seq_str(L, s):
+    buf = C.create_string_buffer(s.size + 1)
+    L.orc_seq_str(C.byref(s), buf)
+    return buf.value.decode()
+
+
+def test_sequence_kats(golden):
+    """test/include_test/sequence_test.cpp:12-45 restated as data: Sequence's selector, operator+, str and operator!
+    -- the operators `if (s < !s) continue` (debruijn_graph_constructor.hpp:279) is written in."""
+    g = golden["sequence_kats"]
+    L = _seq_api()
+    keep = []
+
+    def mk(t):
+        b = t.encode()
+        keep.append(b)
+        return L.orc_seq_make(b)
+    for seq, i, exp in g["selector"]:
+        s = mk(seq)
+        assert "ACGT"[L.orc_seq_at(C.byref(s), i)] == exp
+    for seq, n in g["zero_length"]:
+        assert mk(seq).size == n
+    for seq, exp in g["null_value"] + g["reverse_complement"]:
+        s = mk(seq)
+        r = L.orc_seq_rc(C.byref(s))
+        assert _seq_str(L, r) == exp == rc(seq)
+        rr = L.orc_seq_rc(C.byref(r))
+        assert _seq_str(L, rr) == seq
+    for a, b, exp in g["sum"]:
+        sa, sb = mk(a), mk(b)
+        buf = C.create_string_buffer(len(a) + len(b) + 1)
+        L.orc_seq_concat(C.byref(sa), C.byref(sb), buf)
+        assert buf.value.decode() == exp
+    for seq in g["str"]:
+        assert _seq_str(L, mk(seq)) == seq
+
+
+def test_sequence_views_against_strings():
+    """Subseq and operator< of views (incl. reversed ones) against plain string arithmetic; and the orientation rule
+    of the unitig extractor: a string is kept iff not (s < !s) <=> s >= rc(s) as strings."""
+    L = _seq_api()
+    rng = np.random.default_rng(11)
+    for _ in range(300):
+        n = int(rng.integers(1, 80))
+        t = "".join("ACGT"[i] for i in rng.integers(0, 4, size=n))
+        b = t.encode()
+        s = L.orc_seq_make(b)
+        r = L.orc_seq_rc(C.byref(s))
+        a0, a1 = sorted(int(v) for v in rng.integers(0, n + 1, size=2))
+        assert _seq_str(L, L.orc_seq_subseq(C.byref(s), a0, a1)) == t[a0:a1]
+        assert _seq_str(L, L.orc_seq_subseq(C.byref(r), a0, a1)) == rc(t)[a0:a1]
+        assert bool(L.orc_seq_less(C.byref(s), C.byref(r))) == (t < rc(t))
+        assert bool(L.orc_seq_eq(C.byref(s), C.byref(r))) == (t == rc(t))
+        pre = L.orc_seq_subseq(C.byref(s), 0, a1)
+        assert bool(L.orc_seq_less(C.byref(pre), C.byref(s))) == (t[:a1] < t)  # shorter prefix first
+    # kept orientation of every unitig the oracle emits: s >= rc(s)
+    from tests.helpers import synth_reads
+    u = O.ExtIndex(synth_reads(200, read_len=100, genome_len=1500, seed=3), 21, 1).unitigs()
+    for sq in u.seqs:
+        b = sq.encode()
+        s = L.orc_seq_make(b)
+        r = L.orc_seq_rc(C.byref(s))
+        assert not L.orc_seq_less(C.byref(s), C.byref(r))
+
+
+def test_nucl_kats(golden):
+    """test/include_test/nucl_test.cpp:10-33"""
+    g = golden["nucl_kats"]
+    L = _seq_api()
+    for code, ch in g["nucl"]:
+        assert L.orc_nucl(code).decode() == ch
+    for ch, code in g["dignucl"]:
+        assert L.orc_dignucl(C.c_char(ch.encode())) == code
+    for a, b in g["complement"]:
+        assert L.orc_complement(a) == b
+    for ch in g["is_nucl_true"]:
+        assert L.orc_is_nucl(C.c_char(ch.encode()))
+    for ch in g["is_nucl_false"]:
+        assert not L.orc_is_nucl(C.c_char(ch.encode()))
