@@ -880,18 +880,16 @@ size_t orc_extindex_clip_tips(orc_extindex *x, size_t length_bound, size_t *clip
     return removed;
 }
 
-int orc_unitigs_extract(orc_extindex *x, orc_unitigs *out) {
-    memset(out, 0, sizeof(*out));
+/* CalculateSequences (:267-286) over the canonical k-mers [lo, hi) of the merged file: what ONE chunk of
+ * ExtractUnbranchingPaths' `#pragma omp parallel for` (:351-375) computes; the masks are only read */
+static int extract_chunk(const orc_extindex *x, size_t lo, size_t hi, orc_unitigs *out) {
     int k = x->k, nw = orc_words(k);
     size_t cap = 0;
     strbuf sb = {0, 0, 0};
     char *rcbuf = NULL;
     size_t rccap = 0;
     int rc = 0;
-
-    /* ExtractUnbranchingPaths / CalculateSequences (:267-286,351-375): canonical k-mers in
-     * merged-file order; AddStartDeEdges (:214-226) */
-    for (size_t i = 0; i < x->n_k && !rc; ++i) {
+    for (size_t i = lo; i < hi && !rc; ++i) {
         kwh_t kh;
         memset(&kh, 0, sizeof(kh));
         memcpy(kh.key.w, x->kmers + i * nw, (size_t)nw * sizeof(uint64_t));
@@ -899,6 +897,7 @@ int orc_unitigs_extract(orc_extindex *x, orc_unitigs *out) {
         kh.minimal = 1;
         uint8_t ext = x->masks[i];
         if (!mask_is_junction(ext)) continue;
+        /* AddStartDeEdges (:214-226) */
         deedge_t starts[8];
         int ns = 0;
         for (int next = 0; next < 4; ++next) {
@@ -934,20 +933,82 @@ int orc_unitigs_extract(orc_extindex *x, orc_unitigs *out) {
             if (unitigs_push(out, &cap, sb.d, sb.n)) rc = -1;
         }
     }
+    free(sb.d);
+    free(rcbuf);
+    return rc;
+}
+
+int orc_unitigs_extract(orc_extindex *x, orc_unitigs *out) { return orc_unitigs_extract_mt(x, out, 1); }
+
+/* nthreads > 1: the path phase runs over 16 * nthreads chunks of the k-mer file in parallel and the per-chunk results
+ * are concatenated in chunk order, as ExtractUnbranchingPaths does (:351-375); CleanCondensed (:298-304) is a parallel
+ * loop in the reference too.  The result does not depend on nthreads (the reference's does, through its chunk
+ * boundaries being page-aligned file offsets: only the order of the paths, never the set). */
+int orc_unitigs_extract_mt(orc_extindex *x, orc_unitigs *out, int nthreads) {
+    memset(out, 0, sizeof(*out));
+    int k = x->k, nw = orc_words(k);
+    size_t cap = 0;
+    strbuf sb = {0, 0, 0};
+    char *rcbuf = NULL;
+    size_t rccap = 0;
+    int rc = 0;
+    if (nthreads < 1) nthreads = 1;
+
+    {
+        const size_t nchunks = nthreads == 1 ? 1 : (size_t)16 * (size_t)nthreads;
+        orc_unitigs *parts = (orc_unitigs *)calloc(nchunks, sizeof(orc_unitigs));
+        if (!parts) return -1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+        for (size_t c = 0; c < nchunks; ++c) {
+            const size_t lo = x->n_k * c / nchunks, hi = x->n_k * (c + 1) / nchunks;
+            const int r = extract_chunk(x, lo, hi, &parts[c]);
+            if (r) {
+#pragma omp atomic write
+                rc = r;
+            }
+        }
+        size_t total = 0;
+        for (size_t c = 0; c < nchunks; ++c) total += parts[c].n;
+        if (!rc && total) {
+            out->seq = (char **)malloc(total * sizeof(char *));
+            out->len = (size_t *)malloc(total * sizeof(size_t));
+            if (!out->seq || !out->len) rc = -1;
+        }
+        for (size_t c = 0; c < nchunks; ++c) {
+            if (!rc) {
+                for (size_t j = 0; j < parts[c].n; ++j) {
+                    out->seq[out->n] = parts[c].seq[j];
+                    out->len[out->n] = parts[c].len[j];
+                    out->n++;
+                }
+            } else {
+                for (size_t j = 0; j < parts[c].n; ++j) free(parts[c].seq[j]);
+            }
+            free(parts[c].seq);
+            free(parts[c].len);
+        }
+        free(parts);
+        cap = out->n;
+        if (rc) return rc;
+    }
     size_t n_paths = out->n;
 
-    /* CleanCondensed(result) (:298-304) */
-    for (size_t i = 0; i < n_paths && !rc; ++i) {
+    /* CleanCondensed(result) (:298-304): a parallel loop in the reference as well; every write is "mask := 0" */
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 64)
+    for (size_t i = 0; i < n_paths; ++i) {
         size_t n = out->len[i];
-        if (n + 1 > rccap) {
-            rccap = n * 2 + 16;
-            char *p = (char *)realloc(rcbuf, rccap);
-            if (!p) { rc = -1; break; }
-            rcbuf = p;
+        char *rb = (char *)malloc(n + 1);
+        int r = rb ? 0 : -1;
+        if (!r) {
+            str_rc(out->seq[i], n, rb);
+            r = clean_condensed(x, out->seq[i], n);
+            if (!r) r = clean_condensed(x, rb, n);
         }
-        str_rc(out->seq[i], n, rcbuf);
-        if ((rc = clean_condensed(x, out->seq[i], n))) break;
-        rc = clean_condensed(x, rcbuf, n);
+        free(rb);
+        if (r) {
+#pragma omp atomic write
+            rc = r;
+        }
     }
 
     /* CollectLoops (:308-344) */

@@ -139,6 +139,7 @@ typedef struct {
 
 /* Destroys the masks of x (CleanCondensed), as the reference does. */
 int orc_unitigs_extract(orc_extindex *x, orc_unitigs *out);
+int orc_unitigs_extract_mt(orc_extindex *x, orc_unitigs *out, int nthreads); /* :351-375: chunks in parallel */
 void orc_unitigs_free(orc_unitigs *u);
 
 /* ---- graph ids + GFA text (debruijn_graph_constructor.hpp:390-518, io/graph/gfa_writer.cpp:18-52) ---- */

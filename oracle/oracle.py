@@ -230,9 +230,10 @@ class ExtIndex:
         self.masks = np.ctypeslib.as_array(s.masks, shape=(s.n_k,)).copy() if s.n_k else np.zeros(0, np.uint8)
         return int(removed), int(links.value)
 
-    def unitigs(self):
-        """Runs UnbranchingPathExtractor (destroys the masks held in C, like the reference)."""
-        return Unitigs(self)
+    def unitigs(self, threads=1):
+        """Runs UnbranchingPathExtractor (destroys the masks held in C, like the reference).  threads > 1: the path
+        phase over 16 * threads chunks in parallel (debruijn_graph_constructor.hpp:351-375); same result."""
+        return Unitigs(self, threads)
 
     def __del__(self):
         try:
@@ -242,10 +243,10 @@ class ExtIndex:
 
 
 class Unitigs:
-    def __init__(self, ext):
+    def __init__(self, ext, threads=1):
         self._ext = ext
         self._st = _Unitigs()
-        rc = lib().orc_unitigs_extract(C.byref(ext._st), C.byref(self._st))
+        rc = lib().orc_unitigs_extract_mt(C.byref(ext._st), C.byref(self._st), int(threads))
         if rc != 0:
             raise RuntimeError("orc_unitigs_extract failed: %d" % rc)
         s = self._st

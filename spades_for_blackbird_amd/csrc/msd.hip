@@ -112,6 +112,14 @@ struct PartLevel {
     uint32_t spill_cap;
     // narrow stage A (8-byte keys, 2k - 32 = narrow_hb in [1, 10]): 4-byte records between the levels, see "narrow" below
     int narrow_hb;
+    // narrow level 1: every segment slot is cut into 2^xcd_shift sub-slots of sub_cap records, one per XCD, with a
+    // cursor each (cursor[(bin << xcd_shift) + xcc]).  A (tile, bin) run is ~60 bytes and starts wherever the last one
+    // ended; with one fill front per bin the two halves of a 32-byte sector come from workgroups on different XCDs,
+    // whose L2s each write their part back (1.5x the algorithmic bytes reached HBM).  With a fill front per (bin, XCD)
+    // the partial sectors meet in ONE L2 and leave it complete.  Level 2 reads the sub-slots as segments of their own
+    // and sends them to the buckets of the parent segment.
+    int xcd_shift;
+    uint32_t sub_cap;
 };
 
 // ---- narrow records (stage A, 17 <= k <= 21) ---------------------------------------------------------------
@@ -1916,6 +1924,11 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
     const uint32_t tid = threadIdx.x;
     const uint32_t k_ = (uint32_t)S.k;
     const int hb = L.narrow_hb;
+    uint32_t xcc = 0;  // the XCD this workgroup runs on (placement is for speed only: any value gives a correct result)
+    if (L.xcd_shift) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= (1u << L.xcd_shift) - 1u;
+    }
     lhist[tid] = 0;  // NT == MAXB
     if (tid < MW) mark[tid] = 0ull;
 #ifdef BBK_PHASE_PROF
@@ -1989,7 +2002,7 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
     lstart[tid] = ex;
     uint32_t greserve = 0;
     if (c) {
-        greserve = atomicAdd(&cursor[tid], c);
+        greserve = atomicAdd(&cursor[(tid << L.xcd_shift) + xcc], c);
         nz[nzbase + (uint32_t)__popcll(nzb & ((1ull << lane) - 1ull))] = (uint16_t)tid;
         atomicOr(&mark[ex >> 6], 1ull << (ex & 63u));
     }
@@ -2006,7 +2019,9 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
     goff[tid] = greserve - ex;
     {
         // first staged position of this bin that no longer fits its slot
-        const int64_t room = (int64_t)((uint64_t)tid * L.slot_stride + L.slot_cap) - (int64_t)greserve;
+        const uint64_t slot_end = L.xcd_shift ? (uint64_t)tid * L.slot_stride + (uint64_t)(xcc + 1u) * L.sub_cap
+                                              : (uint64_t)tid * L.slot_stride + L.slot_cap;
+        const int64_t room = (int64_t)slot_end - (int64_t)greserve;
         lhist[tid] = (uint32_t)(int32_t)(room < -(int64_t)0x7FFF0000 ? -(int64_t)0x7FFF0000 : room) + ex;
     }
     if (wave == 0) {  // marks before every 64-position word: lane l owns words WPL*l .. WPL*l + WPL-1
@@ -2181,7 +2196,7 @@ static size_t part_narrow2_smem(bool has_val) {
 
 // level-2 tile descriptors of the narrow path: like k_tile_desc, with the segment id beside the bin count
 __global__ void k_tile_desc_narrow(TileMap M, const uint32_t *__restrict__ seg_nb2, const uint32_t *__restrict__ seg_bin_start,
-                                   uint32_t tile_size, uint4 *__restrict__ desc) {
+                                   uint32_t tile_size, int sub_shift, uint4 *__restrict__ desc) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M.ntiles) return;
     uint32_t lo = 0, hi = M.nseg;
@@ -2192,7 +2207,8 @@ __global__ void k_tile_desc_narrow(TileMap M, const uint32_t *__restrict__ seg_n
     }
     const uint32_t b = M.seg_off[lo] + (t - M.seg_tile_start[lo]) * tile_size;
     const uint32_t e = M.seg_off[lo] + M.seg_size[lo];
-    desc[t] = make_uint4(b, (e - b) < tile_size ? (e - b) : tile_size, seg_nb2[lo] | (lo << 16), seg_bin_start[lo]);
+    const uint32_t seg = lo >> sub_shift;  // M's entries are the per-XCD sub-slots of the level-1 segments
+    desc[t] = make_uint4(b, (e - b) < tile_size ? (e - b) : tile_size, seg_nb2[seg] | (seg << 16), seg_bin_start[seg]);
 }
 
 // Dedup of one bucket of 4-byte records in an LDS table (32-bit ds_cmpst); the distinct records leave as 8-byte keys
@@ -2676,7 +2692,15 @@ struct MsdRunner {
                             getenv("BBK_NO_DIRECT") == nullptr && (double)N / fill * 1.1 + (double)N < 4.2e9;
         const bool slots = hslots || kslots;
         BBK_REQUIRE(!narrow || slots, BBK_ERR_INTERNAL, "narrow records need the slot mode");
-        const uint32_t seg_cap = slots ? ((uint32_t)((double)N / nb1 * (kslots ? 1.06 : 1.01)) + 8192u) | 1u : 0u;
+        // narrow level 1: one sub-slot (and cursor) per XCD inside every segment slot (PartLevel::xcd_shift); the XCDs do
+        // not take exactly equal shares of the tiles, so the sub-slots get 6 % + 2048 records of slack
+        static const bool no_xcd = getenv("BBK_NO_XCD_SLOTS") != nullptr;  // A/B switch
+        const int xs = (narrow && !no_xcd) ? 3 : 0;
+        const uint32_t nsub = nb1 << xs;  // level-1 cursors = level-2 input segments
+        const uint32_t sub_cap = xs ? ((uint32_t)((double)N / nsub * 1.06) + 2048u) | 1u : 0u;
+        const uint32_t seg_cap = !slots ? 0u
+                                 : xs ? sub_cap << xs
+                                      : ((uint32_t)((double)N / nb1 * (kslots ? 1.06 : 1.01)) + 8192u) | 1u;
         const uint32_t cap2 = narrow ? (uint32_t)(kNwHashThreads * kNwHashItems) : bucket_cap();
         // bucket slots 256 B further apart than their capacity: with a power-of-two-ish stride every bucket's
         // fill front sits in the same HBM channel (level-2 scatter measured 10 % slower)
@@ -2697,12 +2721,15 @@ struct MsdRunner {
             L1.spill_count = spill_n.as<uint32_t>();
             L1.spill_cap = spill_cap;
             L1.narrow_hb = narrow ? nw_hb : 0;
+            L1.xcd_shift = xs;
+            L1.sub_cap = sub_cap;
         }
 
         // ---- level 1: histogram (exact mode), offsets, scatter
-        DevBuf hist1((size_t)nb1 * 4 + 16), cur1((size_t)nb1 * 4 + 16);
+        // (off1 / tstart / hsub are per level-1 CURSOR: per segment, or per (segment, XCD) sub-slot on the narrow path)
+        DevBuf hist1((size_t)nb1 * 4 + 16), cur1((size_t)nsub * 4 + 16);
         const Key<W> *kin = (const Key<W> *)d_keys;
-        std::vector<uint32_t> h1(nb1), off1(nb1 + 1), tstart(nb1 + 1), snb2(nb1), sbin(nb1 + 1);
+        std::vector<uint32_t> h1(nb1), off1(nsub + 1), tstart(nsub + 1), snb2(nb1), sbin(nb1 + 1), hsub(nsub), fill1(nsub);
         std::vector<uint32_t> over_seg;  // slot mode: segments that ran over (reprocessed as a whole)
         if (!slots) {
             BBK_HIP(hipMemsetAsync(hist1.p, 0, (size_t)nb1 * 4 + 16, ctx->stream));
@@ -2733,9 +2760,10 @@ struct MsdRunner {
             }
         } else {
             BBK_REQUIRE((uint64_t)nb1 * seg_cap + N < (1ull << 32), BBK_ERR_INTERNAL, "slot layout exceeds 32-bit offsets");
-            for (uint32_t b = 0; b <= nb1; ++b) off1[b] = b * seg_cap;
+            for (uint32_t s2 = 0; s2 <= nsub; ++s2)
+                off1[s2] = xs ? (s2 >> xs) * seg_cap + (s2 & ((1u << xs) - 1u)) * sub_cap : s2 * seg_cap;
         }
-        BBK_HIP(hipMemcpyAsync(cur1.p, off1.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(cur1.p, off1.data(), (size_t)nsub * 4, hipMemcpyHostToDevice, ctx->stream));
 
         const uint64_t nA = slots ? (uint64_t)nb1 * seg_cap : N;  // records bufA holds (slot layout has gaps)
         DevBuf bufA(nA * rec_ab), bufB, valA, valB;
@@ -2770,33 +2798,39 @@ struct MsdRunner {
         }
         if (slots) {
             // the cursors tell what every segment received
-            std::vector<uint32_t> c1(nb1);
-            BBK_HIP(hipMemcpyAsync(c1.data(), cur1.p, (size_t)nb1 * 4, hipMemcpyDeviceToHost, ctx->stream));
+            std::vector<uint32_t> c1(nsub);
+            BBK_HIP(hipMemcpyAsync(c1.data(), cur1.p, (size_t)nsub * 4, hipMemcpyDeviceToHost, ctx->stream));
             BBK_HIP(hipStreamSynchronize(ctx->stream));
             uint64_t got = 0;
+            const uint32_t cap1 = xs ? sub_cap : seg_cap;
             for (uint32_t b = 0; b < nb1; ++b) {
-                const uint32_t reserved = c1[b] - off1[b];
-                got += reserved;
-                if (reserved > seg_cap) {
-                    over_seg.push_back(b);
-                    h1[b] = 0;  // kept out of level 2
-                } else {
-                    h1[b] = reserved;
+                bool over = false;
+                uint32_t tot = 0;
+                for (uint32_t s2 = b << xs; s2 < (b + 1) << xs; ++s2) {
+                    const uint32_t reserved = c1[s2] - off1[s2];
+                    got += reserved;
+                    over = over || reserved > cap1;
+                    fill1[s2] = std::min(reserved, cap1);  // what the slot really holds
+                    tot += fill1[s2];
                 }
+                if (over) over_seg.push_back(b);
+                // an overflowing segment is kept out of level 2 as a whole: every record of a key must meet in one bucket
+                h1[b] = over ? 0u : tot;
+                for (uint32_t s2 = b << xs; s2 < (b + 1) << xs; ++s2) hsub[s2] = over ? 0u : fill1[s2];
             }
             if (got > Ntot) {  // cannot be: every instance reserves one place.  Say what was read before failing
-                std::vector<uint32_t> c2(nb1);
-                BBK_HIP(hipMemcpyAsync(c2.data(), cur1.p, (size_t)nb1 * 4, hipMemcpyDeviceToHost, ctx->stream));
+                std::vector<uint32_t> c2(nsub);
+                BBK_HIP(hipMemcpyAsync(c2.data(), cur1.p, (size_t)nsub * 4, hipMemcpyDeviceToHost, ctx->stream));
                 BBK_HIP(hipStreamSynchronize(ctx->stream));
                 uint32_t shown = 0, differ = 0;
-                for (uint32_t b = 0; b < nb1; ++b) differ += c1[b] != c2[b];
-                for (uint32_t b = 0; b < nb1 && shown < 8; ++b)
+                for (uint32_t b = 0; b < nsub; ++b) differ += c1[b] != c2[b];
+                for (uint32_t b = 0; b < nsub && shown < 8; ++b)
                     if (c1[b] - off1[b] > 2 * seg_cap) {
                         fprintf(stderr, "[bbk] level-1 cursor %u: start %u now %u (second read %u), slot capacity %u\n", b,
                                 off1[b], c1[b], c2[b], seg_cap);
                         ++shown;
                     }
-                fprintf(stderr, "[bbk] level-1 cursors: %u of %u differ between two reads; cur1 at %p\n", differ, nb1, cur1.p);
+                fprintf(stderr, "[bbk] level-1 cursors: %u of %u differ between two reads; cur1 at %p\n", differ, nsub, cur1.p);
                 BBK_REQUIRE(false, BBK_ERR_INTERNAL, "level-1 reservations exceed the instance space (%llu vs %llu)",
                             (unsigned long long)got, (unsigned long long)Ntot);
             }
@@ -2815,32 +2849,34 @@ struct MsdRunner {
                 return 4;
             }
         }
+        if (!slots)
+            for (uint32_t b = 0; b < nb1; ++b) hsub[b] = h1[b];  // exact mode: one dense run per segment
         tstart[0] = 0;
         sbin[0] = 0;
         const uint32_t tile2 = narrow ? (uint32_t)(has_val ? Nw2Cfg<true>::TILE : Nw2Cfg<false>::TILE) : kPartTileK;
+        for (uint32_t s2 = 0; s2 < nsub; ++s2) tstart[s2 + 1] = tstart[s2] + (hsub[s2] + tile2 - 1) / tile2;
         for (uint32_t b = 0; b < nb1; ++b) {
-            tstart[b + 1] = tstart[b] + (h1[b] + tile2 - 1) / tile2;
             snb2[b] = (uint32_t)std::min<double>(kMaxBins, std::max(1.0, std::ceil((double)h1[b] / target)));
             sbin[b + 1] = sbin[b] + snb2[b];
         }
         const uint32_t nbuckets = sbin[nb1];
 
         // ---- level 2
-        DevBuf seg_tile(((size_t)nb1 + 1) * 4), seg_off(((size_t)nb1 + 1) * 4), seg_nb2((size_t)nb1 * 4 + 16),
-            seg_bin(((size_t)nb1 + 1) * 4), seg_size((size_t)nb1 * 4 + 16);
-        BBK_HIP(hipMemcpyAsync(seg_tile.p, tstart.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-        BBK_HIP(hipMemcpyAsync(seg_off.p, off1.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        DevBuf seg_tile(((size_t)nsub + 1) * 4), seg_off(((size_t)nsub + 1) * 4), seg_nb2((size_t)nb1 * 4 + 16),
+            seg_bin(((size_t)nb1 + 1) * 4), seg_size((size_t)nsub * 4 + 16);
+        BBK_HIP(hipMemcpyAsync(seg_tile.p, tstart.data(), ((size_t)nsub + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(seg_off.p, off1.data(), ((size_t)nsub + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(seg_nb2.p, snb2.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(seg_bin.p, sbin.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-        BBK_HIP(hipMemcpyAsync(seg_size.p, h1.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, ctx->stream));
+        BBK_HIP(hipMemcpyAsync(seg_size.p, hsub.data(), (size_t)nsub * 4, hipMemcpyHostToDevice, ctx->stream));
         PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), sel.lo, sel.span, sel.shl, sel.mul};
-        const uint32_t ntiles2 = tstart[nb1];
-        TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), seg_size.as<uint32_t>(), nb1, N, ntiles2, 1, nullptr, 0, 0};
+        const uint32_t ntiles2 = tstart[nsub];
+        TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), seg_size.as<uint32_t>(), nsub, N, ntiles2, 1, nullptr, 0, 0};
         DevBuf desc2((size_t)ntiles2 * sizeof(uint4) + 16);
         if (ntiles2) {
             if (narrow)
                 hipLaunchKernelGGL(k_tile_desc_narrow, dim3((ntiles2 + 255) / 256), dim3(256), 0, ctx->stream, M2,
-                                   seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), tile2, desc2.as<uint4>());
+                                   seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), tile2, xs, desc2.as<uint4>());
             else
                 hipLaunchKernelGGL(k_tile_desc, dim3((ntiles2 + 255) / 256), dim3(256), 0, ctx->stream, M2, seg_nb2.as<uint32_t>(),
                                    seg_bin.as<uint32_t>(), kPartTileK, desc2.as<uint4>());
@@ -3077,7 +3113,9 @@ struct MsdRunner {
                     bkt_fill[i] = std::min<uint32_t>(cap2, cur2[g] - g * stride2);
                 }
             }
-            uint64_t n_extra = (uint64_t)n_spill + (uint64_t)over_seg.size() * seg_cap;
+            uint64_t n_extra = (uint64_t)n_spill;
+            for (uint32_t b : over_seg)
+                for (uint32_t s2 = b << xs; s2 < (b + 1) << xs; ++s2) n_extra += fill1[s2];
             for (uint32_t f : bkt_fill) n_extra += f;
             if (verbose)
                 fprintf(stderr, "[bbk] msd slots%s N=%llu nb1=%u seg_cap=%u buckets=%u spill=%u over_seg=%zu over_bkt=%zu\n",
@@ -3116,7 +3154,9 @@ struct MsdRunner {
                     o += cnt;
                 };
                 put(spill_k.p, spill_v.as<uint32_t>(), 0, n_spill);
-                for (uint32_t b : over_seg) put(bufA.p, valA.as<uint32_t>(), (uint64_t)b * seg_cap, seg_cap, narrow ? (int)b : -1);
+                for (uint32_t b : over_seg)  // the written part of its slot (of every per-XCD sub-slot on the narrow path)
+                    for (uint32_t s2 = b << xs; s2 < (b + 1) << xs; ++s2)
+                        put(bufA.p, valA.as<uint32_t>(), (uint64_t)off1[s2], fill1[s2], narrow ? (int)b : -1);
                 for (size_t i = 0; i < over_bkt.size(); ++i)
                     put(bufB.p, valB.as<uint32_t>(), (uint64_t)over_bkt[i] * stride2, bkt_fill[i],
                         narrow ? (int)h_bseg[over_bkt[i]] : -1);

@@ -64,7 +64,7 @@ def _graph64():
     x._L.bbk_extindex_export(ctx._h, x._h, None, B.engine._ptr(xm))
     pop = torch.tensor([bin(i).count("1") for i in range(16)], dtype=torch.int64, device="cuda")
     n_junction = links_expected = bits = 0
-    zero_masks = 0
+    zero_masks, first_zero = 0, None
     for a0 in range(0, n, 1 << 28):
         m = xm[a0:a0 + (1 << 28)]
         outs, ins = pop[(m & 15).long()], pop[(m >> 4).long()]
@@ -72,11 +72,15 @@ def _graph64():
         n_junction += int(j.sum().item())
         links_expected += int((outs * ins)[j].sum().item())
         bits += int(outs.sum().item()) + int(ins.sum().item())
-        zero_masks += int((m == 0).sum().item())
+        z = m == 0
+        if first_zero is None and bool(z.any().item()):
+            first_zero = a0 + int(torch.nonzero(z)[0].item())
+        zero_masks += int(z.sum().item())
+        del z
         del m, outs, ins, j
     del xm
     torch.cuda.empty_cache()
-    assert zero_masks == 0
+    assert zero_masks == 0, (zero_masks, first_zero, n)
     # every distinct canonical (k+1)-mer sets one out bit (on its prefix k-mer) and one in bit (on its suffix k-mer,
     # kmer_extension_index_builder.hpp:44-59); a (k+1)-mer that is its own reverse complement sets the same bit twice:
     # a uniform 22-mer is one with probability 4^-11, i.e. ~n_e * 2.4e-7 of them
