@@ -271,6 +271,51 @@ int bbk_unitigs_write_fastg(bbk_ctx *ctx, const bbk_unitigs *u, const char *path
 int bbk_unitigs_write_spades(bbk_ctx *ctx, const bbk_unitigs *u, const char *basename);
 void bbk_unitigs_free(bbk_unitigs *u);
 
+
+/* ---- several GPUs of one node in one process (bbk_ctx_create(devices, ndev); 8e: the exchange) --------
+ * The reference tools are one process for the whole job with hash buckets owned by worker threads
+ * (projects/kmercount/main.cpp:186-228, utils/kmer_mph/kmer_buckets.hpp:28-33); here the owner of a canonical k-mer is a
+ * GPU, owner(key) = mulhi(mix(key), ndev).  A group names the devices and holds what they need to talk to each other;
+ * every rank is driven by ITS OWN host thread, which creates its context with bbk_ctx_create(bbk_group_device(g, rank))
+ * and makes all calls for that rank.  The bbk_group_* calls below that take a rank are COLLECTIVE: every rank's thread
+ * calls them once, in the same order (like the grouped ncclSend/ncclRecv they issue).  If a rank fails inside one, the
+ * others return BBK_ERR_INTERNAL instead of waiting for ever. */
+typedef struct bbk_group bbk_group;
+#define BBK_EXCHANGE_RCCL 0u /* one grouped ncclSend/ncclRecv all-to-all over xGMI, messages <= 256 MiB (librccl is loaded
+                                at this point, not before; devices must be distinct) */
+#define BBK_EXCHANGE_COPY 1u /* the same segments moved by peer copies (hipMemcpyPeerAsync); ranks may share a device:
+                                the way to run the N-rank path on one GPU */
+int bbk_group_create(const int *devices, int ndev, unsigned exchange, bbk_group **out);
+int bbk_group_size(const bbk_group *g);
+int bbk_group_device(const bbk_group *g, int rank);
+void bbk_group_destroy(bbk_group *g);
+/* a rank that cannot reach its next collective call (input error, ...) tells the others */
+void bbk_group_abort(bbk_group *g);
+/* local: this rank's distinct canonical k-mers in any order (bbk_count*(BBK_CANONICAL | BBK_UNSORTED [| BBK_WITH_COUNTS]))
+ * -> *shard: the canonical k-mers this rank owns, merged over all ranks (multiplicities summed);
+ * flags: BBK_UNSORTED keeps hash-bucket order (enough for bbk_kmerset_both_strands_ex), 0 sorts ascending. */
+int bbk_group_exchange_kmers(bbk_group *g, int rank, bbk_ctx *ctx, const bbk_kmerset *local, unsigned flags,
+                             bbk_kmerset **shard);
+/* local: BBK_CANONICAL | BBK_UNSORTED | BBK_WITH_MASKS records -> this rank's shard of the extension index (ascending
+ * canonical k-mers it owns with their complete InOutMask): "ext records follow their k-mer's owner, no second exchange" */
+int bbk_group_exchange_extindex(bbk_group *g, int rank, bbk_ctx *ctx, const bbk_kmerset *local_masks,
+                                bbk_extindex **shard);
+/* all shards -> one index on rank dst (*full; NULL on the other ranks): the unitig walk crosses owners */
+int bbk_group_gather_extindex(bbk_group *g, int rank, bbk_ctx *ctx, const bbk_extindex *shard, int dst,
+                              bbk_extindex **full);
+/* the same for a sharded set with multiplicities -> one ascending set on rank dst (gbuilder -c: the (k+1)-mer counts) */
+int bbk_group_gather_kmers(bbk_group *g, int rank, bbk_ctx *ctx, const bbk_kmerset *shard, int dst, bbk_kmerset **full);
+
+/* Device memory of the calling thread's allocator on the context's device: bytes mapped now, bytes mapped since the
+ * process started (growth is what a first call pays: ~30 ms/GiB when the driver has to clear the memory first), seconds
+ * spent mapping, and the device's free / total bytes as the driver reports them.  Any pointer may be NULL. */
+int bbk_ctx_memory_stats(bbk_ctx *ctx, uint64_t *mapped_now, uint64_t *mapped_total, double *map_seconds,
+                         uint64_t *device_free, uint64_t *device_total);
+/* XXH3 bucket boundaries of a set stored in the final_kmers order: h_offsets[b] = first record of bucket b (b = 0..16,
+ * h_offsets[16] = size); what a writer that merges several shards into one final_kmers file needs
+ * (KMerDiskStorage::merge, kmer_index_builder.hpp:168-181) */
+int bbk_kmerset_bucket_offsets(bbk_ctx *ctx, const bbk_kmerset *s, uint64_t *h_offsets);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbbk.so")
-SOURCES = ["primitives.hip", "msd.hip", "superk.hip", "reads.hip", "count.hip", "extindex.hip", "tipclip.hip", "readfilter.hip", "unitigs.hip"]
+SOURCES = ["primitives.hip", "msd.hip", "superk.hip", "reads.hip", "count.hip", "extindex.hip", "tipclip.hip", "readfilter.hip", "unitigs.hip", "group.hip"]
 HEADERS = ["bbk_internal.h", "kmer_ops.h", "msd.h", "accum.h", "arena.h", os.path.join("..", "..", "include", "bbk.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fopenmp", "-Wall", "-Wno-unused-function"]

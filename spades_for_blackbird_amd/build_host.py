@@ -9,7 +9,7 @@ BIN = os.path.join(HERE, "bin")
 PROGRAMS = {"spades-kmercount": "kmercount_main.cpp", "spades-gbuilder": "gbuilder_main.cpp",
             "spades-kmer-estimating": "kmer_estimating_main.cpp", "spades-read-filter": "read_filter_main.cpp",
             "bbk-fastx-dump": "fastx_dump_main.cpp"}
-HEADERS = ["common.hpp", "dataset.hpp", "fastx.hpp", "ingest.hpp"]
+HEADERS = ["common.hpp", "dataset.hpp", "fastx.hpp", "ingest.hpp", "multi.hpp"]
 
 
 def build(force=False, verbose=False):

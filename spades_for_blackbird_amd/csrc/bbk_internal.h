@@ -62,7 +62,8 @@ void *pool_alloc(size_t bytes, size_t *granted, int *device);  // on the current
 void pool_free(void *p, size_t bytes, int device);
 void pool_trim(int device);  // gives the free memory this (device, host thread) holds back to the driver
 void pool_report();          // allocator statistics to stderr
-size_t pool_mapped_bytes(int device);  // device memory the arenas of all host threads hold mapped on `device`
+size_t pool_mapped_bytes(int device);
+void pool_stats(int device, uint64_t *mapped_now, uint64_t *mapped_total, double *map_seconds);  // calling thread's arenas  // device memory the arenas of all host threads hold mapped on `device`
 
 // Owning device buffer.
 struct DevBuf {
@@ -110,6 +111,20 @@ struct DevBuf {
         return reinterpret_cast<T *>(p);
     }
 };
+
+// hipMemcpyAsync for device-to-device / default-kind copies of any size, issued in pieces of at most 1 GiB.  ONE byte
+// copy of 4.97 GB (the u8 masks of an index above 2^32 k-mers into the caller's buffer) arrived with holes on this
+// platform -- a quarter to all of every 256 MiB stretch beyond the first 512 MiB was never written
+// (profiles/r03/d2d_copy_above_4GiB.log), while the same bytes as u32 and the 40 GB of keys next to them arrived whole.
+inline hipError_t copy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t stream) {
+    constexpr size_t kPiece = 1ull << 30;
+    for (size_t o = 0; o < bytes; o += kPiece) {
+        const size_t sz = bytes - o < kPiece ? bytes - o : kPiece;
+        const hipError_t e = hipMemcpyAsync((char *)dst + o, (const char *)src + o, sz, kind, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 // std::vector whose resize() does not zero-fill (multi-hundred-MB host buffers that are about to
 // be overwritten by a device-to-host copy)

@@ -123,6 +123,22 @@ __global__ __launch_bounds__(256) void k_order_check(const Key<W> *__restrict__ 
     }
 }
 
+// one thread per bucket boundary b = 0..16 of a set in the final_kmers order (XXH3 bucket ids never decrease):
+// out[b] = first record whose bucket is >= b
+template <int W>
+__global__ void k_bucket_bounds(const Key<W> *__restrict__ keys, uint64_t n, unsigned long long *__restrict__ out) {
+    const uint32_t b = threadIdx.x;
+    if (b > 16) return;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        const uint32_t bm = (uint32_t)__umul64hi(xxh3_64<W>(key_load<W>(&keys[mid])), 16ull);
+        if (bm < b) lo = mid + 1;
+        else hi = mid;
+    }
+    out[b] = lo;
+}
+
 template <int W>
 static void launch_extract(bbk_ctx *ctx, const bbk_reads *rd, const uint64_t *koff, int k, void *out, uint32_t *vals,
                            uint64_t n_inst) {
@@ -224,10 +240,10 @@ void dedup_reads(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_mask, 
     keys.release();
     vals.release();
     out_keys.alloc(D * rec + 16);
-    BBK_HIP(hipMemcpyAsync(out_keys.p, tmp.p, D * rec, hipMemcpyDeviceToDevice, ctx->stream));
+    BBK_HIP(bbk::copy_async(out_keys.p, tmp.p, D * rec, hipMemcpyDeviceToDevice, ctx->stream));
     if (rv) {
         out_vals.alloc(D * 4 + 16);
-        BBK_HIP(hipMemcpyAsync(out_vals.p, rv, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        BBK_HIP(bbk::copy_async(out_vals.p, rv, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
     BBK_HIP(hipStreamSynchronize(ctx->stream));
     n_distinct = D;
@@ -240,21 +256,21 @@ static uint64_t lsd_sort_unique(bbk_ctx *ctx, unsigned k, const void *d_keys, co
     const size_t rec = (size_t)W * 8;
     BBK_REQUIRE(n < (1ull << 32), BBK_ERR_ARG, "%llu records exceed the LSD path's 2^32-1", (unsigned long long)n);
     DevBuf a(n * rec), b(n * rec), ca, cb;
-    BBK_HIP(hipMemcpyAsync(a.p, d_keys, n * rec, hipMemcpyDeviceToDevice, ctx->stream));
+    BBK_HIP(bbk::copy_async(a.p, d_keys, n * rec, hipMemcpyDeviceToDevice, ctx->stream));
     if (d_vals) {
         ca.alloc(n * 4);
         cb.alloc(n * 4);
-        BBK_HIP(hipMemcpyAsync(ca.p, d_vals, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        BBK_HIP(bbk::copy_async(ca.p, d_vals, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
     sort_records(ctx, W, a.p, b.p, d_vals ? ca.as<uint32_t>() : nullptr, d_vals ? cb.as<uint32_t>() : nullptr, n,
                  key_passes(k));
     const uint64_t D = unique_records(ctx, W, a.p, d_vals ? ca.as<uint32_t>() : nullptr, n, b.p,
                                       d_vals ? cb.as<uint32_t>() : nullptr, rop, false);
     out_keys.alloc(D * rec + 16);
-    BBK_HIP(hipMemcpyAsync(out_keys.p, b.p, D * rec, hipMemcpyDeviceToDevice, ctx->stream));
+    BBK_HIP(bbk::copy_async(out_keys.p, b.p, D * rec, hipMemcpyDeviceToDevice, ctx->stream));
     if (d_vals) {
         out_vals.alloc(D * 4 + 16);
-        BBK_HIP(hipMemcpyAsync(out_vals.p, cb.p, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        BBK_HIP(bbk::copy_async(out_vals.p, cb.p, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
     BBK_HIP(hipStreamSynchronize(ctx->stream));
     return D;
@@ -380,9 +396,9 @@ void Accum::merge() {
     uint64_t o = 0;
     auto put = [&](DevBuf &kb, DevBuf &vb, uint64_t cnt) {
         if (!cnt) return;
-        BBK_HIP(hipMemcpyAsync(ck.as<char>() + o * rec, kb.p, cnt * rec, hipMemcpyDeviceToDevice, ctx->stream));
+        BBK_HIP(bbk::copy_async(ck.as<char>() + o * rec, kb.p, cnt * rec, hipMemcpyDeviceToDevice, ctx->stream));
         if (has_vals())
-            BBK_HIP(hipMemcpyAsync(cv.as<uint32_t>() + o, vb.p, cnt * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            BBK_HIP(bbk::copy_async(cv.as<uint32_t>() + o, vb.p, cnt * 4, hipMemcpyDeviceToDevice, ctx->stream));
         o += cnt;
         BBK_HIP(hipStreamSynchronize(ctx->stream));
         kb.release();
@@ -460,10 +476,10 @@ static void expand_both_strands(bbk_ctx *ctx, unsigned k, const DevBuf &ck, cons
     ec.release();
     s.n = D2;
     s.keys.alloc(D2 * rec);
-    BBK_HIP(hipMemcpyAsync(s.keys.p, et.p, D2 * rec, hipMemcpyDeviceToDevice, ctx->stream));
+    BBK_HIP(bbk::copy_async(s.keys.p, et.p, D2 * rec, hipMemcpyDeviceToDevice, ctx->stream));
     if (wc) {
         s.counts.alloc(D2 * 4);
-        BBK_HIP(hipMemcpyAsync(s.counts.p, ect.p, D2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        BBK_HIP(bbk::copy_async(s.counts.p, ect.p, D2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
     BBK_HIP(hipStreamSynchronize(ctx->stream));
 }
@@ -647,11 +663,11 @@ int bbk_kmerset_from_device_ex(bbk_ctx *ctx, const void *d_keys, const void *d_c
             }
         }
         DevBuf a(n * rec), b(n * rec), ca, cb;
-        BBK_HIP(hipMemcpyAsync(a.p, d_keys, n * rec, hipMemcpyDeviceToDevice, ctx->stream));
+        BBK_HIP(bbk::copy_async(a.p, d_keys, n * rec, hipMemcpyDeviceToDevice, ctx->stream));
         if (d_counts) {
             ca.alloc(n * 4);
             cb.alloc(n * 4);
-            BBK_HIP(hipMemcpyAsync(ca.p, d_counts, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            BBK_HIP(bbk::copy_async(ca.p, d_counts, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
         }
         sort_records(ctx, (int)s->W, a.p, b.p, d_counts ? ca.as<uint32_t>() : nullptr,
                      d_counts ? cb.as<uint32_t>() : nullptr, n, key_passes(k));
@@ -660,10 +676,10 @@ int bbk_kmerset_from_device_ex(bbk_ctx *ctx, const void *d_keys, const void *d_c
                                           d_counts ? REDUCE_SUM : REDUCE_COUNT, false);
         s->n = D;
         s->keys.alloc(D * rec);
-        BBK_HIP(hipMemcpyAsync(s->keys.p, b.p, D * rec, hipMemcpyDeviceToDevice, ctx->stream));
+        BBK_HIP(bbk::copy_async(s->keys.p, b.p, D * rec, hipMemcpyDeviceToDevice, ctx->stream));
         if (d_counts) {
             s->counts.alloc(D * 4);
-            BBK_HIP(hipMemcpyAsync(s->counts.p, cb.p, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            BBK_HIP(bbk::copy_async(s->counts.p, cb.p, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
         }
         BBK_HIP(hipStreamSynchronize(ctx->stream));
         *out = s.release();
@@ -733,22 +749,22 @@ static void export_ordered(bbk_ctx *ctx, const bbk_kmerset *s, const PassDesc *p
     if (s->ref_order && !pd) {
         // ascending export of a set stored in the final_kmers order: sort a copy (not a hot path)
         DevBuf a(s->n * rec), b(s->n * rec), ca, cb;
-        BBK_HIP(hipMemcpyAsync(a.p, s->keys.p, s->n * rec, hipMemcpyDeviceToDevice, ctx->stream));
+        BBK_HIP(bbk::copy_async(a.p, s->keys.p, s->n * rec, hipMemcpyDeviceToDevice, ctx->stream));
         if (wc) {
             ca.alloc(s->n * 4);
             cb.alloc(s->n * 4);
-            BBK_HIP(hipMemcpyAsync(ca.p, s->counts.p, s->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            BBK_HIP(bbk::copy_async(ca.p, s->counts.p, s->n * 4, hipMemcpyDeviceToDevice, ctx->stream));
         }
         sort_records(ctx, (int)s->W, a.p, b.p, wc ? ca.as<uint32_t>() : nullptr, wc ? cb.as<uint32_t>() : nullptr, s->n,
                      key_passes(s->k));
-        BBK_HIP(hipMemcpyAsync(dst_keys, a.p, s->n * rec, hipMemcpyDefault, ctx->stream));
-        if (wc) BBK_HIP(hipMemcpyAsync(dst_counts, ca.p, s->n * 4, hipMemcpyDefault, ctx->stream));
+        BBK_HIP(bbk::copy_async(dst_keys, a.p, s->n * rec, hipMemcpyDefault, ctx->stream));
+        if (wc) BBK_HIP(bbk::copy_async(dst_counts, ca.p, s->n * 4, hipMemcpyDefault, ctx->stream));
         BBK_HIP(hipStreamSynchronize(ctx->stream));
         return;
     }
     if (!pd || (s->ref_order && pd->kind == 1 && pd->nb == 16)) {  // stored in the requested order: plain copy
-        BBK_HIP(hipMemcpyAsync(dst_keys, s->keys.p, s->n * rec, hipMemcpyDefault, ctx->stream));
-        if (wc) BBK_HIP(hipMemcpyAsync(dst_counts, s->counts.p, s->n * 4, hipMemcpyDefault, ctx->stream));
+        BBK_HIP(bbk::copy_async(dst_keys, s->keys.p, s->n * rec, hipMemcpyDefault, ctx->stream));
+        if (wc) BBK_HIP(bbk::copy_async(dst_counts, s->counts.p, s->n * 4, hipMemcpyDefault, ctx->stream));
         BBK_HIP(hipStreamSynchronize(ctx->stream));
         return;
     }
@@ -825,6 +841,26 @@ int bbk_kmerset_verify_order(bbk_ctx *ctx, const bbk_kmerset *s, uint64_t *n_run
             std::sort(h + 2, h + 2 + got);
             for (unsigned i = 0; i < got && i + 1 < cap; ++i) h_run_starts[i + 1] = h[2 + i] + 1;
         }
+    });
+}
+
+int bbk_kmerset_bucket_offsets(bbk_ctx *ctx, const bbk_kmerset *s, uint64_t *h_offsets) {
+    return guarded([&] {
+        BBK_REQUIRE(ctx && s && h_offsets, BBK_ERR_ARG, "bbk_kmerset_bucket_offsets: NULL argument");
+        BBK_REQUIRE(s->ref_order, BBK_ERR_ARG, "bbk_kmerset_bucket_offsets: the set is not in the final_kmers order");
+        BBK_HIP(hipSetDevice(ctx->device));
+        if (s->n == 0) {
+            for (int b = 0; b <= 16; ++b) h_offsets[b] = 0;
+            return;
+        }
+        DevBuf d(17 * 8);
+        BBK_DISPATCH_W(s->W, hipLaunchKernelGGL((k_bucket_bounds<W_>), dim3(1), dim3(64), 0, ctx->stream,
+                                                (const Key<W_> *)s->keys.p, s->n, (unsigned long long *)d.p));
+        check_launch("k_bucket_bounds");
+        unsigned long long h[17];
+        BBK_HIP(hipMemcpyAsync(h, d.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        BBK_HIP(hipStreamSynchronize(ctx->stream));
+        for (int b = 0; b <= 16; ++b) h_offsets[b] = h[b];
     });
 }
 

@@ -167,13 +167,13 @@ int bbk_extindex_export_u32(bbk_ctx *ctx, const bbk_extindex *x, void *dst_keys,
         BBK_REQUIRE(ctx && x, BBK_ERR_ARG, "bbk_extindex_export_u32: NULL argument");
         BBK_HIP(hipSetDevice(ctx->device));
         if (x->n == 0) return;
-        if (dst_keys) BBK_HIP(hipMemcpyAsync(dst_keys, x->keys.p, x->n * x->W * 8, hipMemcpyDefault, ctx->stream));
+        if (dst_keys) BBK_HIP(bbk::copy_async(dst_keys, x->keys.p, x->n * x->W * 8, hipMemcpyDefault, ctx->stream));
         if (dst_masks_u32) {
             DevBuf m(x->n * 4);
             hipLaunchKernelGGL(k_u8_to_u32, dim3((unsigned)((x->n + 255) / 256)), dim3(256), 0, ctx->stream,
                                x->masks.as<uint8_t>(), x->n, m.as<uint32_t>());
             check_launch("k_u8_to_u32");
-            BBK_HIP(hipMemcpyAsync(dst_masks_u32, m.p, x->n * 4, hipMemcpyDefault, ctx->stream));
+            BBK_HIP(bbk::copy_async(dst_masks_u32, m.p, x->n * 4, hipMemcpyDefault, ctx->stream));
             BBK_HIP(hipStreamSynchronize(ctx->stream));
         }
         BBK_HIP(hipStreamSynchronize(ctx->stream));
@@ -221,8 +221,8 @@ int bbk_extindex_export(bbk_ctx *ctx, const bbk_extindex *x, void *dst_keys, voi
         BBK_HIP(hipSetDevice(ctx->device));
         if (x->n == 0) return;
         if (dst_keys)
-            BBK_HIP(hipMemcpyAsync(dst_keys, x->keys.p, x->n * x->W * 8, hipMemcpyDefault, ctx->stream));
-        if (dst_masks) BBK_HIP(hipMemcpyAsync(dst_masks, x->masks.p, x->n, hipMemcpyDefault, ctx->stream));
+            BBK_HIP(bbk::copy_async(dst_keys, x->keys.p, x->n * x->W * 8, hipMemcpyDefault, ctx->stream));
+        if (dst_masks) BBK_HIP(bbk::copy_async(dst_masks, x->masks.p, x->n, hipMemcpyDefault, ctx->stream));
         BBK_HIP(hipStreamSynchronize(ctx->stream));
     });
 }

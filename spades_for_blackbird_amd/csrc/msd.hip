@@ -2901,7 +2901,7 @@ struct MsdRunner {
             hipLaunchKernelGGL(k_scan_to_u32, dim3((nbuckets + 1 + 255) / 256), dim3(256), 0, ctx->stream,
                                h64.as<uint64_t>(), (uint64_t)nbuckets, tot, boff.as<uint32_t>());
             check_launch("k_scan_to_u32");
-            BBK_HIP(hipMemcpyAsync(hist2.p, boff.p, (size_t)nbuckets * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            BBK_HIP(bbk::copy_async(hist2.p, boff.p, (size_t)nbuckets * 4, hipMemcpyDeviceToDevice, ctx->stream));
             BBK_HIP(hipStreamSynchronize(ctx->stream));
         } else {
             // cursor of bucket g starts at its slot
@@ -3146,10 +3146,10 @@ struct MsdRunner {
                                            ek.as<uint64_t>() + o);
                         check_launch("k_nw_widen");
                     } else
-                    BBK_HIP(hipMemcpyAsync(ek.as<char>() + o * rec, (const char *)ksrc + first * rec, cnt * rec,
+                    BBK_HIP(bbk::copy_async(ek.as<char>() + o * rec, (const char *)ksrc + first * rec, cnt * rec,
                                            hipMemcpyDeviceToDevice, ctx->stream));
                     if (has_val)
-                        BBK_HIP(hipMemcpyAsync(ev.as<uint32_t>() + o, vsrc + first, cnt * 4, hipMemcpyDeviceToDevice,
+                        BBK_HIP(bbk::copy_async(ev.as<uint32_t>() + o, vsrc + first, cnt * 4, hipMemcpyDeviceToDevice,
                                                ctx->stream));
                     o += cnt;
                 };
@@ -3255,9 +3255,9 @@ struct MsdRunner {
                                  key_passes(k));
                     const uint64_t d = unique_records(ctx, W, kb, has_val ? vb : nullptr, cnt, ok.p,
                                                       op != MSD_OP_NONE ? ov.as<uint32_t>() : nullptr, rop, false);
-                    BBK_HIP(hipMemcpyAsync(kb, ok.p, d * rec, hipMemcpyDeviceToDevice, ctx->stream));
+                    BBK_HIP(bbk::copy_async(kb, ok.p, d * rec, hipMemcpyDeviceToDevice, ctx->stream));
                     if (op != MSD_OP_NONE)
-                        BBK_HIP(hipMemcpyAsync(vb, ov.p, d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                        BBK_HIP(bbk::copy_async(vb, ov.p, d * 4, hipMemcpyDeviceToDevice, ctx->stream));
                     BBK_HIP(hipStreamSynchronize(ctx->stream));
                     hd[b] = (uint32_t)d;
                 }
@@ -3300,10 +3300,10 @@ struct MsdRunner {
             check_launch("k_compact");
         }
         if (extra.n) {
-            BBK_HIP(hipMemcpyAsync(out.keys.as<char>() + D * rec, extra.keys.p, extra.n * rec, hipMemcpyDeviceToDevice,
+            BBK_HIP(bbk::copy_async(out.keys.as<char>() + D * rec, extra.keys.p, extra.n * rec, hipMemcpyDeviceToDevice,
                                    ctx->stream));
             if (out_vals)
-                BBK_HIP(hipMemcpyAsync(out.vals.as<uint32_t>() + D, extra.vals.p, extra.n * 4, hipMemcpyDeviceToDevice,
+                BBK_HIP(bbk::copy_async(out.vals.as<uint32_t>() + D, extra.vals.p, extra.n * 4, hipMemcpyDeviceToDevice,
                                        ctx->stream));
         }
         // bucket table (exact HASH mode only): offsets of every bucket in the dense output
@@ -3651,10 +3651,10 @@ struct MsdRunner {
             // the slot mode sizes a part for the worst case (every record distinct): keep what is used
             if (pt.keys.bytes > pt.n * rec + (64u << 20)) {
                 DevBuf ek(pt.n * rec + 16), ev;
-                BBK_HIP(hipMemcpyAsync(ek.p, pt.keys.p, pt.n * rec, hipMemcpyDeviceToDevice, ctx->stream));
+                BBK_HIP(bbk::copy_async(ek.p, pt.keys.p, pt.n * rec, hipMemcpyDeviceToDevice, ctx->stream));
                 if (out_vals) {
                     ev.alloc(pt.n * 4 + 16);
-                    BBK_HIP(hipMemcpyAsync(ev.p, pt.vals.p, pt.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                    BBK_HIP(bbk::copy_async(ev.p, pt.vals.p, pt.n * 4, hipMemcpyDeviceToDevice, ctx->stream));
                 }
                 BBK_HIP(hipStreamSynchronize(ctx->stream));
                 pt.keys = std::move(ek);
@@ -3668,10 +3668,10 @@ struct MsdRunner {
         uint64_t o = 0;
         for (auto &p : parts) {
             if (p.n) {
-                BBK_HIP(hipMemcpyAsync(out.keys.as<char>() + o * rec, p.keys.p, p.n * rec, hipMemcpyDeviceToDevice,
+                BBK_HIP(bbk::copy_async(out.keys.as<char>() + o * rec, p.keys.p, p.n * rec, hipMemcpyDeviceToDevice,
                                        ctx->stream));
                 if (out_vals)
-                    BBK_HIP(hipMemcpyAsync(out.vals.as<uint32_t>() + o, p.vals.p, p.n * 4, hipMemcpyDeviceToDevice,
+                    BBK_HIP(bbk::copy_async(out.vals.as<uint32_t>() + o, p.vals.p, p.n * 4, hipMemcpyDeviceToDevice,
                                            ctx->stream));
             }
             o += p.n;

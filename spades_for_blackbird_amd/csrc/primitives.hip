@@ -227,6 +227,18 @@ void pool_report() {
             (double)retired / 1e9, (unsigned long long)pool().generations);
 }
 
+void pool_stats(int device, uint64_t *mapped_now, uint64_t *mapped_total, double *map_seconds) {
+    std::lock_guard<std::mutex> g(pool().mu);
+    const PoolKey key{device, std::this_thread::get_id()};
+    uint64_t now = 0;
+    auto it = pool().arenas.find(key);
+    if (it != pool().arenas.end())
+        for (auto &A : it->second.gens) now += A->mapped;
+    if (mapped_now) *mapped_now = now;
+    if (mapped_total) *mapped_total = (uint64_t)pool().malloc_bytes;
+    if (map_seconds) *map_seconds = pool().malloc_s;
+}
+
 size_t pool_mapped_bytes(int device) {
     std::lock_guard<std::mutex> g(pool().mu);
     size_t mapped = 0;
@@ -876,8 +888,8 @@ static void sort_impl(bbk_ctx *ctx, Key<W> *keys, Key<W> *tmp, uint32_t *vals, u
         std::swap(vsrc, vdst);
     }
     if (src != keys) {
-        BBK_HIP(hipMemcpyAsync(keys, src, n * sizeof(Key<W>), hipMemcpyDeviceToDevice, ctx->stream));
-        if (vals) BBK_HIP(hipMemcpyAsync(vals, vsrc, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        BBK_HIP(bbk::copy_async(keys, src, n * sizeof(Key<W>), hipMemcpyDeviceToDevice, ctx->stream));
+        if (vals) BBK_HIP(bbk::copy_async(vals, vsrc, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     }
     BBK_HIP(hipStreamSynchronize(ctx->stream));  // hist/chunk are freed on return
 }
@@ -1238,6 +1250,21 @@ int bbk_ctx_trim(bbk_ctx *ctx) {
         BBK_HIP(hipSetDevice(ctx->device));
         BBK_HIP(hipStreamSynchronize(ctx->stream));
         bbk::pool_trim(ctx->device);
+    });
+}
+
+int bbk_ctx_memory_stats(bbk_ctx *ctx, uint64_t *mapped_now, uint64_t *mapped_total, double *map_seconds,
+                         uint64_t *device_free, uint64_t *device_total) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx != nullptr, BBK_ERR_ARG, "bbk_ctx_memory_stats: ctx is NULL");
+        BBK_HIP(hipSetDevice(ctx->device));
+        bbk::pool_stats(ctx->device, mapped_now, mapped_total, map_seconds);
+        if (device_free || device_total) {
+            size_t f = 0, t = 0;
+            BBK_HIP(hipMemGetInfo(&f, &t));
+            if (device_free) *device_free = f;
+            if (device_total) *device_total = t;
+        }
     });
 }
 

@@ -1063,7 +1063,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
         }
         const uint64_t n_rec = exclusive_scan_u64(ctx, boff.as<uint64_t>(), boff.as<uint64_t>(), nbuckets);
         BBK_HIP(hipMemcpyAsync(boff.as<uint64_t>() + nbuckets, &n_rec, 8, hipMemcpyHostToDevice, ctx->stream));
-        BBK_HIP(hipMemcpyAsync(cur2.p, boff.p, (size_t)nbuckets * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        BBK_HIP(bbk::copy_async(cur2.p, boff.p, (size_t)nbuckets * 8, hipMemcpyDeviceToDevice, ctx->stream));
         BBK_HIP(hipMemcpyAsync(hflags, dflags.p, 64, hipMemcpyDeviceToHost, ctx->stream));
         BBK_HIP(hipStreamSynchronize(ctx->stream));  // n_rec is a stack variable; level-1 flags
         if (hflags[SKF_SLOT1] || hflags[SKF_STAGE] || hflags[SKF_SELECT]) return declined(pass);
@@ -1172,10 +1172,10 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
                 if (cursor_now + mo.n > out_cap) {  // room for the appended records
                     const uint64_t new_cap = cursor_now + mo.n + (N - std::min<uint64_t>(N, cursor_now + mo.n)) / 8;
                     DevBuf nkeys(new_cap * key_bytes + 16), nvals;
-                    BBK_HIP(hipMemcpyAsync(nkeys.p, okeys.p, cursor_now * key_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    BBK_HIP(bbk::copy_async(nkeys.p, okeys.p, cursor_now * key_bytes, hipMemcpyDeviceToDevice, ctx->stream));
                     if (op != MSD_OP_NONE) {
                         nvals.alloc(new_cap * 4 + 16);
-                        BBK_HIP(hipMemcpyAsync(nvals.p, ovals.p, cursor_now * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                        BBK_HIP(bbk::copy_async(nvals.p, ovals.p, cursor_now * 4, hipMemcpyDeviceToDevice, ctx->stream));
                     }
                     BBK_HIP(hipStreamSynchronize(ctx->stream));
                     okeys = std::move(nkeys);
@@ -1183,10 +1183,10 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
                     out_cap = new_cap;
                 }
                 if (mo.n) {
-                    BBK_HIP(hipMemcpyAsync(okeys.as<char>() + cursor_now * key_bytes, mo.keys.p, mo.n * key_bytes,
+                    BBK_HIP(bbk::copy_async(okeys.as<char>() + cursor_now * key_bytes, mo.keys.p, mo.n * key_bytes,
                                            hipMemcpyDeviceToDevice, ctx->stream));
                     if (op != MSD_OP_NONE)
-                        BBK_HIP(hipMemcpyAsync(ovals.as<uint32_t>() + cursor_now, mo.vals.p, mo.n * 4, hipMemcpyDeviceToDevice,
+                        BBK_HIP(bbk::copy_async(ovals.as<uint32_t>() + cursor_now, mo.vals.p, mo.n * 4, hipMemcpyDeviceToDevice,
                                                ctx->stream));
                 }
                 cursor_now += mo.n;
@@ -1205,10 +1205,10 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
                 fprintf(stderr, "[bbk] superk: output regrown %llu -> %llu records (pass %u)\n", (unsigned long long)out_cap,
                         (unsigned long long)new_cap, pass);
             DevBuf nkeys(new_cap * key_bytes + 16), nvals;
-            BBK_HIP(hipMemcpyAsync(nkeys.p, okeys.p, done_before * key_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            BBK_HIP(bbk::copy_async(nkeys.p, okeys.p, done_before * key_bytes, hipMemcpyDeviceToDevice, ctx->stream));
             if (op != MSD_OP_NONE) {
                 nvals.alloc(new_cap * 4 + 16);
-                BBK_HIP(hipMemcpyAsync(nvals.p, ovals.p, done_before * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                BBK_HIP(bbk::copy_async(nvals.p, ovals.p, done_before * 4, hipMemcpyDeviceToDevice, ctx->stream));
             }
             BBK_HIP(hipStreamSynchronize(ctx->stream));
             okeys = std::move(nkeys);
@@ -1236,10 +1236,10 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     // the caller keeps the result for the rest of the job: do not leave it in a buffer sized for the estimate
     if (out_cap > D + D / 8 + (1u << 20)) {
         DevBuf xk(D * key_bytes + 16), xv;
-        BBK_HIP(hipMemcpyAsync(xk.p, okeys.p, D * key_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        BBK_HIP(bbk::copy_async(xk.p, okeys.p, D * key_bytes, hipMemcpyDeviceToDevice, ctx->stream));
         if (op != MSD_OP_NONE) {
             xv.alloc(D * 4 + 16);
-            BBK_HIP(hipMemcpyAsync(xv.p, ovals.p, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            BBK_HIP(bbk::copy_async(xv.p, ovals.p, D * 4, hipMemcpyDeviceToDevice, ctx->stream));
         }
         BBK_HIP(hipStreamSynchronize(ctx->stream));
         out_keys = std::move(xk);

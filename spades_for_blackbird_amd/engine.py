@@ -26,6 +26,8 @@ SYMBOLS = [
     "bbk_unitigs_build", "bbk_unitigs_to_reads", "bbk_unitigs_add_coverage", "bbk_unitigs_add_coverage_counts", "bbk_unitigs_export_kc", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
     "bbk_unitigs_vertices", "bbk_unitigs_links", "bbk_unitigs_export", "bbk_unitigs_export_links",
     "bbk_unitigs_write_gfa", "bbk_unitigs_write_fasta", "bbk_unitigs_write_fastg", "bbk_unitigs_write_spades", "bbk_unitigs_free",
+    "bbk_group_create", "bbk_group_size", "bbk_group_device", "bbk_group_destroy", "bbk_group_abort", "bbk_group_exchange_kmers",
+    "bbk_group_exchange_extindex", "bbk_group_gather_extindex", "bbk_group_gather_kmers", "bbk_ctx_memory_stats", "bbk_kmerset_bucket_offsets",
 ]
 
 
@@ -157,6 +159,19 @@ def load_library():
         L.bbk_unitigs_write_fastg.argtypes = [vp, vp, C.c_char_p]
         L.bbk_unitigs_write_spades.argtypes = [vp, vp, C.c_char_p]
         L.bbk_unitigs_free.argtypes = [vp]
+    L.bbk_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_uint, C.POINTER(vp)]
+    L.bbk_group_size.argtypes = [vp]
+    L.bbk_group_device.argtypes = [vp, C.c_int]
+    L.bbk_group_destroy.argtypes = [vp]
+    L.bbk_group_destroy.restype = None
+    L.bbk_group_abort.argtypes = [vp]
+    L.bbk_group_abort.restype = None
+    L.bbk_group_exchange_kmers.argtypes = [vp, C.c_int, vp, vp, C.c_uint, C.POINTER(vp)]
+    L.bbk_group_exchange_extindex.argtypes = [vp, C.c_int, vp, vp, C.POINTER(vp)]
+    L.bbk_group_gather_extindex.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(vp)]
+    L.bbk_group_gather_kmers.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(vp)]
+    L.bbk_ctx_memory_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]
+    L.bbk_kmerset_bucket_offsets.argtypes = [vp, vp, vp]
     _LIB = L
     return L
 
@@ -204,8 +219,19 @@ class Context:
         _check(self._L.bbk_ctx_synchronize(self._h))
 
     def trim(self):
-        """give the allocator's cached device memory back to the driver"""
+        """Gives the device memory the allocator holds but does not use back to the driver (free chunks at the end of
+        the calling thread's arena are unmapped and released).  The next calls map what they need again: ~30 ms/GiB
+        when the driver has to clear the memory first -- trim when another process or library needs the memory, not
+        between the steps of a loop."""
         _check(self._L.bbk_ctx_trim(self._h))
+
+    def memory_stats(self):
+        """dict(mapped_now, mapped_total, map_seconds, device_free, device_total) of this thread's allocator / device"""
+        a, b, f, t = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        sec = C.c_double()
+        _check(self._L.bbk_ctx_memory_stats(self._h, C.byref(a), C.byref(b), C.byref(sec), C.byref(f), C.byref(t)))
+        return {"mapped_now": a.value, "mapped_total": b.value, "map_seconds": sec.value, "device_free": f.value,
+                "device_total": t.value}
 
     def profile(self, on=True):
         _check(self._L.bbk_ctx_profile_enable(self._h, int(on)))

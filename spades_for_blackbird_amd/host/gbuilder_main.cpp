@@ -1,6 +1,6 @@
 // spades-gbuilder drop-in: same argv contract as the reference tool (projects/gbuilder/main.cpp:47-87)
 //   <dataset yaml | fasta/fastq> <output> [-k <int=21>] [-c] [-t <int>] [-tmp-dir <dir>] [-b <bytes>]
-//   one of --unitigs (default) | --fastg | --gfa | --spades            (+ --device <int>, ours)
+//   one of --unitigs (default) | --fastg | --gfa | --spades   (+ --device <int>, --devices a,b,.. [--exchange rccl|copy], ours)
 // and the same flow (:103-237): reads -> extension index -> unbranching paths + loops ->
 // unitig FASTA or graph -> GFA, with every step behind the C ABI (include/bbk.h).
 // -t = parser threads, -b = bytes of input text per block: the reads are streamed block by block through
@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "multi.hpp"
 
 using namespace bbkhost;
 
@@ -28,7 +29,9 @@ static void usage(const char *argv0) {
            "        --fastg     produce graph in FASTG format\n"
            "        --gfa       produce graph in GFA1 format\n"
            "        --spades    produce graph in SPAdes internal format\n"
-           "        --device <value>  GPU to use (default 0)\n",
+           "        --device <value>  GPU to use (default 0)\n"
+           "        --devices <a,b,...>  GPUs to use: extension-index records sharded by k-mer owner over one RCCL all-to-all,\n"
+           "                    the shards gathered on the first device for the unitig stage (--exchange copy: peer copies)\n",
            argv0);
 }
 
@@ -39,6 +42,7 @@ int main(int argc, char **argv) {
     enum { UNITIGS, FASTG, GFA, SPADES } mode = UNITIGS;
     int modes_given = 0;
     std::vector<std::string> pos;
+    std::string devices_arg, exchange_arg = "rccl";
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         unsigned long long v = 0;
@@ -48,6 +52,8 @@ int main(int argc, char **argv) {
         else if (a == "-t") { if (need(&v)) threads = v; else bad = true; }
         else if (a == "-b") { if (need(&v)) bufsize = v; else bad = true; }
         else if (a == "--device") { if (need(&v)) device = (unsigned)v; else bad = true; }
+        else if (a == "--devices") { if (i + 1 < argc) devices_arg = argv[++i]; else bad = true; }
+        else if (a == "--exchange") { if (i + 1 < argc) exchange_arg = argv[++i]; else bad = true; }
         else if (a == "-tmp-dir") { if (i + 1 < argc) ++i; else bad = true; }
         else if (a == "--unitigs") { mode = UNITIGS; ++modes_given; }
         else if (a == "--fastg") { mode = FASTG; ++modes_given; }
@@ -88,15 +94,64 @@ int main(int argc, char **argv) {
         files.push_back(file);
     }
 
+    std::vector<int> devices;
+    if (!devices_arg.empty() && !parse_devices(devices_arg, devices)) fatal("--devices: expected a comma-separated list of GPU indices");
+    if (exchange_arg != "rccl" && exchange_arg != "copy") fatal("--exchange: rccl or copy");
     Phases ph;
     const double t_start = now_s();
     bbk_ctx *ctx = nullptr;
+    const bool want_cov = coverage && mode != UNITIGS;
+    bbk_extindex *ext = nullptr;
+    bbk_kmerset *kp1 = nullptr;  // -c: ascending canonical (k+1)-mers with multiplicities
+    double t0 = 0;
+    if (!devices.empty()) {
+        // ---- several devices: every rank reduces its blocks to (canonical k-mer, OR of mask bits) records, the records go
+        //      to the k-mer's owner in one all-to-all, the owners' shards are gathered on rank 0 for the walk
+        bbk_group *g = nullptr;
+        check(bbk_group_create(devices.data(), (int)devices.size(), exchange_arg == "rccl" ? BBK_EXCHANGE_RCCL : BBK_EXCHANGE_COPY, &g),
+              "bbk_group_create");
+        const int n = bbk_group_size(g);
+        info("Using %d device(s), %s exchange", n, exchange_arg.c_str());
+        std::vector<bbk_counter *> xc((size_t)n, nullptr), cc((size_t)n, nullptr);
+        std::vector<bbk_ctx *> ctxs;
+        RankHooks hooks;
+        hooks.init = [&](int r, bbk_ctx *c) {
+            check(bbk_count_begin(c, k, BBK_CANONICAL | BBK_UNSORTED | BBK_WITH_MASKS, &xc[(size_t)r]), "bbk_count_begin");
+            if (want_cov) check(bbk_count_begin(c, k + 1, BBK_CANONICAL | BBK_UNSORTED | BBK_WITH_COUNTS, &cc[(size_t)r]), "bbk_count_begin");
+        };
+        hooks.push = [&](int r, bbk_ctx *, bbk_reads *rd) {
+            check(bbk_count_push_reads(xc[(size_t)r], rd), "bbk_count_push_reads");
+            if (want_cov) check(bbk_count_push_reads(cc[(size_t)r], rd), "bbk_count_push_reads");
+        };
+        hooks.finish = [&](int r, bbk_ctx *c) {
+            bbk_kmerset *local = nullptr;
+            bbk_extindex *shard = nullptr, *full = nullptr;
+            check(bbk_count_finish(xc[(size_t)r], &local), "bbk_count_finish");
+            check(bbk_group_exchange_extindex(g, r, c, local, &shard), "bbk_group_exchange_extindex");
+            bbk_kmerset_free(local);
+            check(bbk_group_gather_extindex(g, r, c, shard, 0, &full), "bbk_group_gather_extindex");
+            bbk_extindex_free(shard);
+            if (r == 0) ext = full;
+            if (want_cov) {
+                bbk_kmerset *lc = nullptr, *sc = nullptr, *fc = nullptr;
+                check(bbk_count_finish(cc[(size_t)r], &lc), "bbk_count_finish");
+                check(bbk_group_exchange_kmers(g, r, c, lc, BBK_UNSORTED, &sc), "bbk_group_exchange_kmers");
+                bbk_kmerset_free(lc);
+                check(bbk_group_gather_kmers(g, r, c, sc, 0, &fc), "bbk_group_gather_kmers");
+                bbk_kmerset_free(sc);
+                if (r == 0) kp1 = fc;
+            }
+        };
+        const uint64_t n_reads = run_ranks(g, files, (size_t)bufsize, threads ? (int)threads : default_threads(), ph, hooks, ctxs);
+        info("Used %llu reads", (unsigned long long)n_reads);
+        ctx = ctxs[0];
+        t0 = now_s();
+    } else {
     // Step 1: build extension index (:169-172), block by block; with -c the canonical (k+1)-mer multiplicities
     // (CoverageHashMapBuilder, :200-211) are counted from the same blocks.  The context (HIP initialisation:
     // 0.1-0.2 s) and the two accumulators are created while the first block is being parsed.
     bbk_extbuilder *xb = nullptr;
     bbk_counter *covc = nullptr;
-    const bool want_cov = coverage && mode != UNITIGS;
     auto init = [&] {
         const double t0c = now_s();
         check(bbk_ctx_create((int)device, &ctx), "bbk_ctx_create");
@@ -110,9 +165,10 @@ int main(int argc, char **argv) {
             if (covc) check(bbk_count_push_reads(covc, r), "bbk_count_push_reads");
         }, init);
     info("Used %llu reads", (unsigned long long)n_reads);
-    double t0 = now_s();
-    bbk_extindex *ext = nullptr;
+    t0 = now_s();
     check(bbk_extindex_finish(xb, &ext), "bbk_extindex_finish");
+    if (covc) check(bbk_count_finish(covc, &kp1), "bbk_count_finish");
+    }
     info("K-mer counting done. There are %llu kmers in total.", (unsigned long long)bbk_extindex_size(ext));
     info("Building k-mer extensions from k+1-mers finished.");
 
@@ -132,10 +188,8 @@ int main(int argc, char **argv) {
     } else {
         info("Total %llu edges to create", (unsigned long long)(2 * bbk_unitigs_count(u)));
         info("Total %llu vertices to create", (unsigned long long)bbk_unitigs_vertices(u));
-        if (covc) {  // Step 4: infer coverage (projects/gbuilder/main.cpp:200-211)
+        if (kp1) {  // Step 4: infer coverage (projects/gbuilder/main.cpp:200-211)
             info("Filling coverage index");
-            bbk_kmerset *kp1 = nullptr;
-            check(bbk_count_finish(covc, &kp1), "bbk_count_finish");
             check(bbk_unitigs_add_coverage_counts(ctx, u, kp1), "bbk_unitigs_add_coverage_counts");
             bbk_kmerset_free(kp1);
             info("Filling coverage and flanking coverage from PHM");

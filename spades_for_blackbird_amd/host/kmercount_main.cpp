@@ -2,7 +2,7 @@
 // reference tool (projects/kmercount/main.cpp:124-184 for the flags, :186-228 for the flow), with
 // the splitter + KMerDiskCounter replaced by the MI355X engine behind the C ABI (include/bbk.h).
 //   -k/--kmer <int=21>  -d/--dataset <yaml>  -t/--threads <int>  -w/--workdir <dir>
-//   -b/--bufsize <bytes>  -h/--help  [input files...]        (+ --device <int>, ours)
+//   -b/--bufsize <bytes>  -h/--help  [input files...]        (+ --device <int>, --devices a,b,.. [--exchange rccl|copy], ours)
 // -t = parser threads (the reference: OpenMP threads of the splitter); -b = bytes of input text per block (the
 // reference: sorting buffer per thread): the input is streamed through bbk_count_begin / push / finish block by block,
 // so host memory is bounded by two blocks and device memory by one block + the distinct set -- the reference's
@@ -15,6 +15,7 @@
 #include <sys/stat.h>
 
 #include "common.hpp"
+#include "multi.hpp"
 
 using namespace bbkhost;
 
@@ -27,7 +28,9 @@ static void usage(const char *argv0) {
            "        -w, --workdir <dir>     Working directory to use\n"
            "        -b, --bufsize <value>   Sorting buffer size, per thread\n"
            "        -h, --help              Show help\n"
-           "        --device <value>        GPU to use (default 0)\n\n"
+           "        --device <value>        GPU to use (default 0)\n"
+           "        --devices <a,b,...>     GPUs to use: one host thread + context per device, k-mers sharded by owner hash,\n"
+           "                                one RCCL all-to-all after the local count (--exchange copy: peer copies)\n\n"
            "DESCRIPTION\n        SPAdes k-mer counting engine (MI355X)\n\n"
            "        Output: <output_dir>/final_kmers - unordered set of kmers in binary format. Kmers from both forward and\n"
            "        reverse-complementary reads are taken into account.\n\n"
@@ -40,7 +43,7 @@ static void usage(const char *argv0) {
 int main(int argc, char **argv) {
     unsigned K = 21, device = 0;
     unsigned long long threads = 0, bufsize = 536870912ull;  // projects/kmercount/main.cpp:124-130
-    std::string workdir, dataset;
+    std::string workdir, dataset, devices_arg, exchange_arg = "rccl";
     std::vector<std::string> input;
     bool help = false, bad = false;
     for (int i = 1; i < argc; ++i) {
@@ -51,6 +54,8 @@ int main(int argc, char **argv) {
         else if (a == "-t" || a == "--threads") { if (need(&v)) threads = v; else bad = true; }
         else if (a == "-b" || a == "--bufsize") { if (need(&v)) bufsize = v; else bad = true; }
         else if (a == "--device") { if (need(&v)) device = (unsigned)v; else bad = true; }
+        else if (a == "--devices") { if (i + 1 < argc) devices_arg = argv[++i]; else bad = true; }
+        else if (a == "--exchange") { if (i + 1 < argc) exchange_arg = argv[++i]; else bad = true; }
         else if (a == "-d" || a == "--dataset") { if (i + 1 < argc) dataset = argv[++i]; else bad = true; }
         else if (a == "-w" || a == "--workdir") { if (i + 1 < argc) workdir = argv[++i]; else bad = true; }
         else if (a == "-h" || a == "--help") help = true;
@@ -76,8 +81,55 @@ int main(int argc, char **argv) {
         std::string err;
         if (!load_dataset_yaml(dataset, files, err)) fatal("%s", err.c_str());
     }
+    std::vector<int> devices;
+    if (!devices_arg.empty() && !parse_devices(devices_arg, devices)) fatal("--devices: expected a comma-separated list of GPU indices");
+    if (exchange_arg != "rccl" && exchange_arg != "copy") fatal("--exchange: rccl or copy");
     Phases ph;
     const double t_start = now_s();
+    if (!devices.empty()) {
+        // ---- several devices (or one, through the same code): local count -> owner exchange -> per-rank final_kmers order
+        //      -> one file.  The group (RCCL communicators) is set up while the parser reads the first block.
+        bbk_group *g = nullptr;
+        check(bbk_group_create(devices.data(), (int)devices.size(), exchange_arg == "rccl" ? BBK_EXCHANGE_RCCL : BBK_EXCHANGE_COPY, &g),
+              "bbk_group_create");
+        const int n = bbk_group_size(g);
+        info("Using %d device(s), %s exchange", n, exchange_arg.c_str());
+        const unsigned W = bbk_words(K);
+        std::vector<bbk_counter *> counters((size_t)n, nullptr);
+        std::vector<ShardOnHost> shards((size_t)n);
+        std::vector<bbk_ctx *> ctxs;
+        RankHooks hooks;
+        hooks.init = [&](int r, bbk_ctx *c) {
+            check(bbk_count_begin(c, K, BBK_CANONICAL | BBK_UNSORTED, &counters[(size_t)r]), "bbk_count_begin");
+        };
+        hooks.push = [&](int r, bbk_ctx *, bbk_reads *rd) { check(bbk_count_push_reads(counters[(size_t)r], rd), "bbk_count_push_reads"); };
+        hooks.finish = [&](int r, bbk_ctx *c) {
+            bbk_kmerset *local = nullptr, *shard = nullptr, *both = nullptr;
+            check(bbk_count_finish(counters[(size_t)r], &local), "bbk_count_finish");
+            check(bbk_group_exchange_kmers(g, r, c, local, BBK_UNSORTED, &shard), "bbk_group_exchange_kmers");
+            bbk_kmerset_free(local);
+            // a k-mer and its reverse complement share the canonical owner: the shard expands on its own
+            check(bbk_kmerset_both_strands_ex(c, shard, BBK_REFERENCE_ORDER, &both), "bbk_kmerset_both_strands_ex");
+            bbk_kmerset_free(shard);
+            ShardOnHost &sh = shards[(size_t)r];
+            check(bbk_kmerset_bucket_offsets(c, both, sh.off), "bbk_kmerset_bucket_offsets");
+            sh.keys.resize((size_t)bbk_kmerset_size(both) * W);
+            check(bbk_kmerset_export(c, both, BBK_ORDER_REFERENCE_BUCKETS16, sh.keys.data(), nullptr), "bbk_kmerset_export");
+            bbk_kmerset_free(both);
+        };
+        run_ranks(g, files, (size_t)bufsize, threads ? (int)threads : default_threads(), ph, hooks, ctxs);
+        if (!workdir.empty()) mkdir(workdir.c_str(), 0755);
+        const std::string out = (workdir.empty() ? std::string("") : workdir + "/") + "final_kmers";
+        const double t0w = now_s();
+        uint64_t total = 0;
+        if (!write_final_kmers_merged(shards, W, out, &total)) fatal("cannot write %s", out.c_str());
+        ph.write = now_s() - t0w;
+        info("K-mer counting done. There are %llu kmers in total.", (unsigned long long)total);
+        info("K-mer counting done, kmers saved to %s", out.c_str());
+        ph.total = now_s() - t_start;
+        ph.report("spades-kmercount");
+        finish_process(ctxs.empty() ? nullptr : ctxs[0], 0);
+    }
     bbk_ctx *ctx = nullptr;
     bbk_counter *counter = nullptr;
     // the context (HIP initialisation: 0.1-0.2 s) and the counter are created while the first block is being parsed;

@@ -204,3 +204,57 @@ def test_read_filter_cli(bins, golden, golden_dir, tmp_path):
     assert fa.startswith(">" + r1[keep_pairs[0]][0] + "\n") and "+" not in fa.split("\n")[2]
     r = subprocess.run([bins["spades-read-filter"], "-k", "21"], capture_output=True, text=True)
     assert r.returncode == 1 and "SYNOPSIS" in r.stdout  # -d is required
+
+
+# ---- several ranks in one process (--devices): SURVEY 8e / north_star "host code kept in C++ ... single RCCL all-to-all" ----
+def _fasta(path, reads):
+    with open(path, "w") as f:
+        for i, s in enumerate(reads):
+            f.write(">r%d\n%s\n" % (i, s))
+
+
+@pytest.mark.parametrize("k", [21, 33, 77])
+def test_kmercount_cli_devices(bins, tmp_path, k):
+    """One process, one host thread + context per rank, owner-hash shards, one exchange, N-way bucket merge into ONE
+    final_kmers: byte-identical to the single-device tool and to the oracle.  A one-GPU box cannot hold two RCCL ranks
+    (RCCL refuses a device listed twice), so the N-rank logic runs with --exchange copy on devices 0,0[,0] (the same
+    segments, rounds and merge; peer copies instead of ncclSend/ncclRecv) and the RCCL code path with one rank."""
+    from tests.helpers import synth_reads
+    import numpy as np
+    reads = synth_reads(6000, read_len=150, genome_len=30000, sub_rate=0.01, seed=k, n_rate=0.002)
+    fa = tmp_path / "r.fa"
+    _fasta(fa, reads)
+    exp = O.kmercount(reads, k, 16, 2)
+    outs = {}
+    for name, extra, env in (("single", [], {}),
+                             ("rccl1", ["--devices", "0"], {}),
+                             ("copy2", ["--devices", "0,0", "--exchange", "copy"], {}),
+                             ("copy3_small_messages", ["--devices", "0,0,0", "--exchange", "copy"], {"BBK_GROUP_MAX_MSG": "4096"})):
+        wd = tmp_path / name
+        e = dict(os.environ)
+        e.update(env)
+        # -b small: several blocks, so that every rank gets some
+        r = subprocess.run([bins["spades-kmercount"], "-k", str(k), "-t", "4", "-b", "200000", "-w", str(wd), str(fa)] + extra,
+                           capture_output=True, text=True, env=e)
+        assert r.returncode == 0, (name, r.stdout[-2000:], r.stderr[-2000:])
+        assert "There are %d kmers in total" % len(exp) in r.stdout, (name, r.stdout[-1000:])
+        outs[name] = open(wd / "final_kmers", "rb").read()
+    want = np.ascontiguousarray(exp).tobytes()
+    for name, data in outs.items():
+        assert data == want, name
+
+
+def test_gbuilder_cli_devices(bins, tmp_path):
+    from tests.helpers import synth_reads
+    k = 21
+    reads = synth_reads(4000, read_len=150, genome_len=12000, sub_rate=0.005, seed=9)
+    fa = tmp_path / "r.fa"
+    _fasta(fa, reads)
+    exp = O.ExtIndex(reads, k, 1).unitigs().gfa(with_cov=True)[0]
+    for name, extra in (("rccl1", ["--devices", "0"]), ("copy2", ["--devices", "0,0", "--exchange", "copy"]),
+                        ("copy3", ["--devices", "0,0,0", "--exchange", "copy"])):
+        out = tmp_path / (name + ".gfa")
+        r = subprocess.run([bins["spades-gbuilder"], str(fa), str(out), "-k", str(k), "--gfa", "-c", "-b", "150000"] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stdout[-2000:], r.stderr[-2000:])
+        assert gfa_canon.canon_md5(open(out).read(), k, with_kc=True) == gfa_canon.canon_md5(exp, k, with_kc=True), name
