@@ -214,6 +214,13 @@ int bbk_extindex_begin(bbk_ctx *ctx, unsigned k, bbk_extbuilder **out);
 int bbk_extindex_push_reads(bbk_extbuilder *b, const bbk_reads *reads);
 int bbk_extindex_finish(bbk_extbuilder *b, bbk_extindex **out);
 void bbk_extindex_abort(bbk_extbuilder *b);
+/* Count + extension index from ONE pass over the reads (BASELINE configs[2]: both are wanted of the same reads): the
+ * canonical records the index is built from are also the canonical set of the count -- including the k-mers of reads of
+ * length exactly k, which the index drops (they never get an extension bit) and spades-kmercount keeps.
+ * set_flags = BBK_BOTH_STRANDS [| BBK_REFERENCE_ORDER].  Results equal bbk_count / bbk_extindex_build run separately. */
+int bbk_count_extindex(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned set_flags, bbk_kmerset **set,
+                       bbk_extindex **out);
+int bbk_extindex_finish_with_set(bbk_extbuilder *b, unsigned set_flags, bbk_kmerset **set, bbk_extindex **out);
 uint64_t bbk_extindex_size(const bbk_extindex *x);
 unsigned bbk_extindex_k(const bbk_extindex *x);
 /* sorted canonical k-mers (size*words u64) and their InOutMask bytes

@@ -39,6 +39,9 @@ struct Accum {
     uint64_t finish_sorted(DevBuf &out_keys, DevBuf &out_vals);
 };
 
+// count.hip: canon U rc(canon) of the accumulated canonical records (payloads dropped); the accumulator keeps them
+bbk_kmerset *both_strands_of(Accum &acc, unsigned flags);
+
 uint64_t drop_zero_vals(bbk_ctx *ctx, int W, const void *keys, const uint32_t *vals, uint64_t n, DevBuf &out_keys,
                         DevBuf &out_vals);
 

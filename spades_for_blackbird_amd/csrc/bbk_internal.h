@@ -112,19 +112,15 @@ struct DevBuf {
     }
 };
 
-// hipMemcpyAsync for device-to-device / default-kind copies of any size, issued in pieces of at most 1 GiB.  ONE byte
-// copy of 4.97 GB (the u8 masks of an index above 2^32 k-mers into the caller's buffer) arrived with holes on this
-// platform -- a quarter to all of every 256 MiB stretch beyond the first 512 MiB was never written
-// (profiles/r03/d2d_copy_above_4GiB.log), while the same bytes as u32 and the 40 GB of keys next to them arrived whole.
-inline hipError_t copy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t stream) {
-    constexpr size_t kPiece = 1ull << 30;
-    for (size_t o = 0; o < bytes; o += kPiece) {
-        const size_t sz = bytes - o < kPiece ? bytes - o : kPiece;
-        const hipError_t e = hipMemcpyAsync((char *)dst + o, (const char *)src + o, sz, kind, stream);
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
-}
+// Device-to-device / default-kind copies of the library (primitives.hip).  Copies inside the device are done by a
+// KERNEL on the stream, not by the runtime: the u8 masks of an index of 4.97 G k-mers, written by a kernel into arena
+// (virtual-memory-mapped) memory and copied into a caller's hipMalloc'ed buffer with hipMemcpyAsync(hipMemcpyDefault),
+// arrived with a quarter to all of every 256 MiB stretch beyond the first 512 MiB still zero -- as one copy and in
+// 1 GiB pieces alike -- while a kernel reading the same source saw every byte (profiles/r03/d2d_copy_above_4GiB.log).
+// Kernel loads and stores are what the rest of the path uses between any two kernels.  Anything that involves host
+// memory goes through hipMemcpyAsync in pieces of at most 1 GiB.
+hipError_t copy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t stream);
+bool pool_owns(const void *p);  // the address lies in an arena of the allocator
 
 // std::vector whose resize() does not zero-fill (multi-hundred-MB host buffers that are about to
 // be overwritten by a device-to-host copy)

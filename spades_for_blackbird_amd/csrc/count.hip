@@ -532,6 +532,32 @@ static bbk_kmerset *finish_count(Accum &acc, unsigned flags) {
     return s.release();
 }
 
+// The both-strand set of spades-kmercount from an accumulator that is NOT consumed (bbk_extindex_finish_with_set: the
+// extension index is built from the same canonical records afterwards).  The payloads (mask bits) are not carried over.
+bbk_kmerset *both_strands_of(Accum &acc, unsigned flags) {
+    BBK_REQUIRE((flags & BBK_BOTH_STRANDS) && !(flags & (BBK_WITH_COUNTS | BBK_WITH_MASKS | BBK_UNSORTED | BBK_CANONICAL)),
+                BBK_ERR_ARG, "the set built beside an extension index is BBK_BOTH_STRANDS [| BBK_REFERENCE_ORDER]");
+    auto s = std::make_unique<bbk_kmerset>();
+    s->k = acc.k;
+    s->W = words_of(acc.k);
+    s->flags = flags;
+    s->has_counts = false;
+    s->instances = 2 * acc.instances;
+    acc.merge();
+    const bool want_ref = (flags & BBK_REFERENCE_ORDER) != 0;
+    expand_both_strands(acc.ctx, acc.k, acc.keys, nullptr, acc.n, *s, want_ref);
+    if (want_ref && !s->ref_order && s->sorted) {
+        if (s->n) {
+            const PassDesc pd{1, 0, 0, 8, 16};
+            DevBuf nk(s->n * (size_t)s->W * 8);
+            partition_records(acc.ctx, (int)s->W, s->keys.p, nk.p, nullptr, nullptr, s->n, pd);
+            s->keys = std::move(nk);
+        }
+        s->ref_order = true;
+    }
+    return s.release();
+}
+
 static void check_count_flags(unsigned flags) {
     const bool both = (flags & BBK_BOTH_STRANDS) != 0, canon = (flags & BBK_CANONICAL) != 0;
     BBK_REQUIRE(both != canon, BBK_ERR_ARG, "bbk_count: pass exactly one of BBK_BOTH_STRANDS / BBK_CANONICAL");

@@ -22,9 +22,15 @@
 
 namespace bbk {
 
+// four masks per thread, one dword store (the array is padded to a multiple of 16 bytes)
 __global__ void k_u32_to_u8(const uint32_t *__restrict__ in, uint64_t n, uint8_t *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (uint8_t)in[i];
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (i + j < n) w |= (in[i + j] & 0xFFu) << (8 * j);
+    *reinterpret_cast<uint32_t *>(out + i) = w;
 }
 
 // pref[t] = first index whose top `bits` bits of word 0 are >= t  (t in [0, 2^bits]).  IDX = uint32_t below 2^32 - 2
@@ -102,7 +108,7 @@ static bbk_extindex *finish_extindex(Accum &acc) {
     if (!x->keys.p) x->keys.alloc(16);
     x->masks.alloc(x->n + 16);
     if (x->n) {
-        const uint64_t nblk = (x->n + 255) / 256;
+        const uint64_t nblk = ((x->n + 3) / 4 + 255) / 256;
         BBK_REQUIRE(nblk < (1ull << 31), BBK_ERR_ARG, "extension index of %llu k-mers exceeds the launch grid",
                     (unsigned long long)x->n);
         hipLaunchKernelGGL(k_u32_to_u8, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, m32.as<uint32_t>(), x->n,
@@ -208,6 +214,35 @@ int bbk_extindex_finish(bbk_extbuilder *b, bbk_extindex **out) {
     });
     delete b;
     return rc;
+}
+
+// Count + extension index from ONE pass over the reads (BASELINE configs[2]): stage A runs once with the mask payload;
+// its canonical records are (a) expanded to the both-strand set of spades-kmercount -- the k-mers of reads of length
+// exactly k, which carry no extension bit, included -- and (b) ordered, stripped of the records without a bit and
+// turned into the index.  Equal to bbk_count_finish(BBK_BOTH_STRANDS ...) + bbk_extindex_finish on the same pushes.
+int bbk_extindex_finish_with_set(bbk_extbuilder *b, unsigned set_flags, bbk_kmerset **set, bbk_extindex **out) {
+    const int rc = guarded([&] {
+        BBK_REQUIRE(b && set && out, BBK_ERR_ARG, "bbk_extindex_finish_with_set: NULL argument");
+        BBK_HIP(hipSetDevice(b->acc.ctx->device));
+        std::unique_ptr<bbk_kmerset, void (*)(bbk_kmerset *)> s(both_strands_of(b->acc, set_flags), bbk_kmerset_free);
+        *out = finish_extindex(b->acc);
+        *set = s.release();
+    });
+    delete b;
+    return rc;
+}
+
+int bbk_count_extindex(bbk_ctx *ctx, const bbk_reads *reads, unsigned k, unsigned set_flags, bbk_kmerset **set,
+                       bbk_extindex **out) {
+    bbk_extbuilder *b = nullptr;
+    int rc = bbk_extindex_begin(ctx, k, &b);
+    if (rc != BBK_OK) return rc;
+    rc = bbk_extindex_push_reads(b, reads);
+    if (rc != BBK_OK) {
+        bbk_extindex_abort(b);
+        return rc;
+    }
+    return bbk_extindex_finish_with_set(b, set_flags, set, out);
 }
 
 void bbk_extindex_abort(bbk_extbuilder *b) { delete b; }

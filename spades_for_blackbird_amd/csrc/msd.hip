@@ -116,8 +116,8 @@ struct PartLevel {
     // cursor each (cursor[(bin << xcd_shift) + xcc]).  A (tile, bin) run is ~60 bytes and starts wherever the last one
     // ended; with one fill front per bin the two halves of a 32-byte sector come from workgroups on different XCDs,
     // whose L2s each write their part back (1.5x the algorithmic bytes reached HBM).  With a fill front per (bin, XCD)
-    // the partial sectors meet in ONE L2 and leave it complete.  Level 2 reads the sub-slots as segments of their own
-    // and sends them to the buckets of the parent segment.
+    // the partial sectors were expected to meet in ONE L2 and leave it complete (they do not: see the call site).  Level 2
+    // reads the sub-slots as segments of their own and sends them to the buckets of the parent segment.
     int xcd_shift;
     uint32_t sub_cap;
 };
@@ -2694,8 +2694,12 @@ struct MsdRunner {
         BBK_REQUIRE(!narrow || slots, BBK_ERR_INTERNAL, "narrow records need the slot mode");
         // narrow level 1: one sub-slot (and cursor) per XCD inside every segment slot (PartLevel::xcd_shift); the XCDs do
         // not take exactly equal shares of the tiles, so the sub-slots get 6 % + 2048 records of slack
-        static const bool no_xcd = getenv("BBK_NO_XCD_SLOTS") != nullptr;  // A/B switch
-        const int xs = (narrow && !no_xcd) ? 3 : 0;
+        // Measured (profiles/r03/xcd_slots_*): the level-1 kernel 3.96 -> 3.79 ms, but its HBM write traffic did NOT
+        // fall (7.7 -> 8.1 GB for 5.2 GB of records: the partial sectors are not merged in L2 either way), level 2 reads
+        // eight short runs per segment instead of one (2.62 -> 2.70 ms) and the step gains 0.1 ms of 15.3: withdrawn as
+        // the default, kept as an experiment (BBK_XCD_SLOTS=1).
+        static const bool use_xcd = getenv("BBK_XCD_SLOTS") != nullptr;
+        const int xs = (narrow && use_xcd) ? 3 : 0;
         const uint32_t nsub = nb1 << xs;  // level-1 cursors = level-2 input segments
         const uint32_t sub_cap = xs ? ((uint32_t)((double)N / nsub * 1.06) + 2048u) | 1u : 0u;
         const uint32_t seg_cap = !slots ? 0u

@@ -227,6 +227,14 @@ void pool_report() {
             (double)retired / 1e9, (unsigned long long)pool().generations);
 }
 
+bool pool_owns(const void *p) {
+    std::lock_guard<std::mutex> g(pool().mu);
+    for (auto &kv : pool().arenas)
+        for (auto &A : kv.second.gens)
+            if (A->contains(p)) return true;
+    return false;
+}
+
 void pool_stats(int device, uint64_t *mapped_now, uint64_t *mapped_total, double *map_seconds) {
     std::lock_guard<std::mutex> g(pool().mu);
     const PoolKey key{device, std::this_thread::get_id()};
@@ -405,6 +413,51 @@ void pool_trim(int device) {
     pool().free_s += wall_s() - t0;
     pool().frees += it->second.size();
     pool().free_blocks.erase(it);
+}
+
+__global__ __launch_bounds__(256) void k_copy(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
+                                              size_t bytes, int vec16) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    size_t done = 0;
+    if (vec16) {
+        const size_t n16 = bytes >> 4;
+        const uint4 *s = reinterpret_cast<const uint4 *>(src);
+        uint4 *d = reinterpret_cast<uint4 *>(dst);
+        for (size_t j = i; j < n16; j += stride) d[j] = s[j];
+        done = n16 << 4;
+    }
+    for (size_t j = done + i; j < bytes; j += stride) dst[j] = src[j];
+}
+
+static bool is_device_memory(const void *p) {
+    if (pool_owns(p)) return true;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // plain host memory is not an error
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+}
+
+hipError_t copy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    const bool on_device = kind == hipMemcpyDeviceToDevice ||
+                           (kind == hipMemcpyDefault && is_device_memory(dst) && is_device_memory(src));
+    if (on_device && !getenv("BBK_RUNTIME_COPIES")) {  // BBK_RUNTIME_COPIES=1: A/B switch
+        const int vec16 = (((uintptr_t)dst | (uintptr_t)src) & 15u) == 0;
+        const size_t units = vec16 ? (bytes >> 4) + 1 : bytes;
+        const unsigned blocks = (unsigned)std::min<size_t>((units + 255) / 256, 16384);
+        hipLaunchKernelGGL(k_copy, dim3(blocks ? blocks : 1), dim3(256), 0, stream, (const unsigned char *)src,
+                           (unsigned char *)dst, bytes, vec16);
+        return hipGetLastError();
+    }
+    constexpr size_t kPiece = 1ull << 30;
+    for (size_t o = 0; o < bytes; o += kPiece) {
+        const size_t sz = bytes - o < kPiece ? bytes - o : kPiece;
+        const hipError_t e = hipMemcpyAsync((char *)dst + o, (const char *)src + o, sz, kind, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 void d2h_big(bbk_ctx *ctx, void *dst, const void *src, size_t bytes) {

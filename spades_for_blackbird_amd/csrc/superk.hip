@@ -684,8 +684,19 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
                 const uint32_t entry = (tag << 18) | (((uint32_t)KEEP + r) << 7) | (j << 1) | strand;
                 uint32_t slot = h & (uint32_t)(TS - 1);
                 bool done = false;
-                for (uint32_t p = 0; p < kSkdMaxProbes; ++p) {
+                // Two nested loops instead of one: the inner one only walks to the first slot that is empty or carries my
+                // tag (a load and two compares per step); what is expensive -- cutting the entry's k-mer out of its
+                // record and comparing 2W words -- happens in the outer loop, which nearly every lane leaves after ONE
+                // round (a 13-bit tag lets 1 in 8192 foreign entries through).  With the comparison inside a single
+                // probe loop every lane of the wave paid it once per step of the LONGEST chain among the 64 (3-4 steps
+                // at this load): ~250 vector instructions per k-mer for ~60 of straight-line code (SQ counters).
+                for (uint32_t p = 0; p < kSkdMaxProbes && !done;) {
                     uint32_t e = table[slot];
+                    while (e != EMPTY && (e >> 18) != tag && ++p < kSkdMaxProbes) {
+                        slot = (slot + 1u) & (uint32_t)(TS - 1);
+                        e = table[slot];
+                    }
+                    if (p >= kSkdMaxProbes) break;
                     if (e == EMPTY) {
                         e = atomicCAS(&table[slot], EMPTY, entry);
                         if (e == EMPTY) {
@@ -704,6 +715,7 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
                         }
                     }
                     slot = (slot + 1u) & (uint32_t)(TS - 1);
+                    ++p;
                 }
                 if (done) {
                     if (OP == 1) atomicAdd(&tvals[slot], val);

@@ -19,7 +19,7 @@ SYMBOLS = [
     "bbk_reads_get_ascii", "bbk_reads_export_ascii", "bbk_reads_free",
     "bbk_count", "bbk_count_begin", "bbk_count_push_reads", "bbk_count_push_ascii", "bbk_count_finish", "bbk_count_abort",
     "bbk_count_pushed_instances", "bbk_extindex_from_device", "bbk_extindex_export_u32", "bbk_extindex_begin", "bbk_extindex_push_reads", "bbk_extindex_finish",
-    "bbk_extindex_abort", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_kmerset_both_strands_ex", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k", "bbk_kmerset_keys", "bbk_reads_median_filter",
+    "bbk_extindex_abort", "bbk_extindex_finish_with_set", "bbk_count_extindex", "bbk_kmerset_from_device", "bbk_kmerset_from_device_ex", "bbk_kmerset_both_strands", "bbk_kmerset_both_strands_ex", "bbk_words", "bbk_kmerset_size", "bbk_kmerset_k", "bbk_kmerset_keys", "bbk_reads_median_filter",
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_clip_tips", "bbk_extindex_free",
@@ -114,6 +114,8 @@ def load_library():
     L.bbk_extindex_push_reads.argtypes = [vp, vp]
     L.bbk_extindex_finish.argtypes = [vp, C.POINTER(vp)]
     L.bbk_extindex_abort.argtypes = [vp]
+    L.bbk_extindex_finish_with_set.argtypes = [vp, C.c_uint, C.POINTER(vp), C.POINTER(vp)]
+    L.bbk_count_extindex.argtypes = [vp, vp, C.c_uint, C.c_uint, C.POINTER(vp), C.POINTER(vp)]
     L.bbk_kmerset_from_device.argtypes = [vp, vp, vp, u64, C.c_uint, C.POINTER(vp)]
     L.bbk_kmerset_from_device_ex.argtypes = [vp, vp, vp, u64, C.c_uint, C.c_uint, C.POINTER(vp)]
     L.bbk_kmerset_both_strands.argtypes = [vp, vp, C.POINTER(vp)]
@@ -335,6 +337,12 @@ class Context:
         _check(self._L.bbk_extindex_build(self._h, reads._h, k, C.byref(h)))
         return ExtIndex(self, h)
 
+    def count_extindex(self, reads, k, flags=BOTH_STRANDS):
+        """k-mer set (both strands) and extension index from ONE pass over the reads: (KMerSet, ExtIndex)"""
+        hs, hx = C.c_void_p(), C.c_void_p()
+        _check(self._L.bbk_count_extindex(self._h, reads._h, k, flags, C.byref(hs), C.byref(hx)))
+        return KMerSet(self, hs), ExtIndex(self, hx)
+
     def extindex_from_device(self, d_keys, d_masks_u32, n, k):
         """Index of (canonical k-mer, u32 mask) records in HBM: any order, duplicates OR-ed (a shard after the exchange)."""
         h = C.c_void_p()
@@ -527,6 +535,13 @@ class ExtBuilder:
         b, self._h = self._h, None
         _check(self._L.bbk_extindex_finish(b, C.byref(h)))
         return ExtIndex(self.ctx, h)
+
+    def finish_with_set(self, flags=BOTH_STRANDS):
+        """(KMerSet of both strands, ExtIndex) from the one accumulation (bbk_extindex_finish_with_set)"""
+        hs, hx = C.c_void_p(), C.c_void_p()
+        b, self._h = self._h, None
+        _check(self._L.bbk_extindex_finish_with_set(b, flags, C.byref(hs), C.byref(hx)))
+        return KMerSet(self.ctx, hs), ExtIndex(self.ctx, hx)
 
     def abort(self):
         if getattr(self, "_h", None):

@@ -137,19 +137,16 @@ def _configs2_full_size():
                 hi = mid
         assert lo < nx and tuple(int(v) for v in xk[lo].cpu().numpy().view(np.uint64)) == q
     ctx.close()
+    del xk, xk_keep, xm
+    torch.cuda.empty_cache()  # torch's cached blocks go back too: the next tests start subprocesses that need the device
     print("CONFIGS2-OK")
 
 
 def test_configs2_full_size():
-    """Runs in a process of its own: the engine's arena allocator keeps the device memory it has mapped for the life of
-    the process (primitives.hip), and ~230 GB held by the test runner would starve the tests that start subprocesses."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import sys; sys.path.insert(0, %r); from tests.test_gpu_configs2 import _configs2_full_size as f; f()" % root
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
-    if "CONFIGS2-SKIP" in r.stdout:
+    """In-process again (round 3): the allocator unmaps what a trim frees and never re-uses an unmapped address
+    (the round-2 abort after a trim was stale address translations of re-mapped virtual addresses), so the
+    ~230 GB this test maps are back with the driver when it ends and the tests that start subprocesses find them."""
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.mem_get_info()[1] < 250e9:
         pytest.skip("needs the 288 GB of an MI355X")
-    assert "CONFIGS2-OK" in r.stdout
+    _configs2_full_size()

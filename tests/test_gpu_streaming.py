@@ -330,3 +330,35 @@ def test_superk_ragged_reads(k, monkeypatch, capfd):
     err = capfd.readouterr().err
     assert "superk:" in err and "distinct" in err and "declines" not in err
     ctx.close()
+
+
+@pytest.mark.parametrize("k", [21, 33, 55])
+def test_count_and_extindex_from_one_pass(k):
+    """bbk_count_extindex / bbk_extindex_finish_with_set (BASELINE configs[2]: count + DeBruijnExtensionIndex of the same
+    reads): one stage A with the mask payload; results equal the two separate calls and the oracle -- including reads of
+    length exactly k, whose k-mers the index drops (no extension bit, kmer_splitters.hpp:160-180) and spades-kmercount
+    keeps."""
+    import numpy as np
+    import spades_for_blackbird_amd as B
+    from oracle import oracle as O
+    from tests.helpers import synth_reads
+    ctx = B.Context(0)
+    reads = synth_reads(2500, read_len=120, genome_len=9000, sub_rate=0.01, seed=40 + k, n_rate=0.002)
+    reads += ["ACGTTGCA" * 20][0:1] + [("ACGTTGCATTGACCA" * 10)[:k], ("TTGACCAGGTACCAT" * 10)[:k], "", "ACG"]
+    r = ctx.reads_from_ascii(reads)
+    s0 = ctx.count(r, k, B.BOTH_STRANDS | B.REFERENCE_ORDER).export(B.ORDER_REFERENCE_BUCKETS16)
+    k0, m0 = ctx.extindex(r, k).export()
+    s1, x1 = ctx.count_extindex(r, k, B.BOTH_STRANDS | B.REFERENCE_ORDER)
+    assert np.array_equal(s1.export(B.ORDER_REFERENCE_BUCKETS16), s0)
+    k1, m1 = x1.export()
+    assert np.array_equal(k1, k0) and np.array_equal(m1, m0)
+    assert np.array_equal(s0, O.kmercount(reads, k, 16, 2))
+    # streamed in three pushes
+    xb = ctx.extbuilder(k)
+    for part in (reads[:900], reads[900:1800], reads[1800:]):
+        xb.push(ctx.reads_from_ascii(part))
+    s2, x2 = xb.finish_with_set(B.BOTH_STRANDS)
+    assert np.array_equal(s2.export(B.ORDER_REFERENCE_BUCKETS16), s0)
+    k2, m2 = x2.export()
+    assert np.array_equal(k2, k0) and np.array_equal(m2, m0)
+    ctx.close()
