@@ -396,16 +396,21 @@ def main():
 
     def step():
         """Returns (#records of this rank's part of the result, keep-alive)."""
+        if not sharded and args.ext_index:
+            # BASELINE configs[2]: count + DeBruijnExtensionIndex of the same reads from ONE pass over them
+            # (bbk_count_extindex: stage A once with the mask payload; BBK_BENCH_SEPARATE=1: the two calls of round 2)
+            if os.environ.get("BBK_BENCH_SEPARATE") == "1":
+                s = ctx.count(reads, k, B.BOTH_STRANDS | B.REFERENCE_ORDER)
+                n = len(s)
+                s.free()
+                return n, ctx.extindex(reads, k)
+            s, x = ctx.count_extindex(reads, k, B.BOTH_STRANDS | B.REFERENCE_ORDER)
+            return len(s), [s, x]
         if not sharded:
             # the set is built in the final_kmers order (what spades-kmercount leaves on disk) and stays in HBM
             s = ctx.count(reads, k, B.BOTH_STRANDS | B.REFERENCE_ORDER)
             ptr, order = s.device_keys()
             assert order == B.ORDER_REFERENCE_BUCKETS16 and (ptr or len(s) == 0)
-            if args.ext_index:
-                n = len(s)
-                s.free()  # configs[2] sizes: the set (115 GB) and the index (60 GB) are not held together
-                x = ctx.extindex(reads, k)
-                return n, x
             return len(s), s
         both = D.sharded_count(ctx, reads, k, both_strands=True, reference_order=True)
         ptr, order = both.device_keys()

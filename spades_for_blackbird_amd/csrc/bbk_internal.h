@@ -112,13 +112,7 @@ struct DevBuf {
     }
 };
 
-// Device-to-device / default-kind copies of the library (primitives.hip).  Copies inside the device are done by a
-// KERNEL on the stream, not by the runtime: the u8 masks of an index of 4.97 G k-mers, written by a kernel into arena
-// (virtual-memory-mapped) memory and copied into a caller's hipMalloc'ed buffer with hipMemcpyAsync(hipMemcpyDefault),
-// arrived with a quarter to all of every 256 MiB stretch beyond the first 512 MiB still zero -- as one copy and in
-// 1 GiB pieces alike -- while a kernel reading the same source saw every byte (profiles/r03/d2d_copy_above_4GiB.log).
-// Kernel loads and stores are what the rest of the path uses between any two kernels.  Anything that involves host
-// memory goes through hipMemcpyAsync in pieces of at most 1 GiB.
+// Device-to-device / default-kind copies of the library: one place to change how they are done.
 hipError_t copy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t stream);
 bool pool_owns(const void *p);  // the address lies in an arena of the allocator
 
@@ -209,6 +203,18 @@ inline void check_launch(const char *what) {
 }
 
 inline unsigned words_of(unsigned k) { return (k + 31) >> 5; }
+
+// One thread per item over billions of items.  A launch whose x dimension holds 2^32 threads or more is neither refused
+// nor run in full: the thread count is taken modulo 2^32 and the rest of the items is silently skipped (an index of
+// 4 968 413 780 k-mers had its last 4.29 G masks never converted, its start edges never counted:
+// profiles/r03/d2d_copy_above_4GiB.log -- the first untouched item is n - 2^32).  Per-item kernels therefore get their
+// blocks in two dimensions (grid_blocks) and read their item through BBK_GID(); every one of them checks it against n.
+#define BBK_GID() ((((uint64_t)blockIdx.y * gridDim.x) + blockIdx.x) * blockDim.x + threadIdx.x)
+inline dim3 grid_blocks(uint64_t blocks) {
+    constexpr uint64_t kMaxX = 1ull << 21;  // x 1024 threads at most: 2^31 threads in x
+    if (blocks <= kMaxX) return dim3((unsigned)(blocks ? blocks : 1));
+    return dim3((unsigned)kMaxX, (unsigned)((blocks + kMaxX - 1) / kMaxX));
+}
 
 // Large device -> host copy through the context's pinned staging buffers (chunked, two buffers:
 // the copy of chunk i+1 overlaps the host memcpy of chunk i).

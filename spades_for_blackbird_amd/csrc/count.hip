@@ -36,7 +36,7 @@ static bool msd_enabled() {
 
 __global__ void k_kmers_per_read(const uint32_t *__restrict__ len, uint64_t n, uint32_t k,
                                  uint64_t *__restrict__ nk) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i < n) {
         const uint32_t L = len[i];
         nk[i] = L >= k ? (uint64_t)(L - k + 1) : 0ull;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_extract(const uint64_t *__restrict__ wo
                                                 const uint64_t *__restrict__ koff, uint64_t n_reads, int k,
                                                 Key<W> *__restrict__ out, uint32_t *__restrict__ out_val) {
     const int lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t wave = (BBK_GID()) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t r = wave; r < n_reads; r += nwaves) {
         const uint32_t L = len[r];
@@ -90,7 +90,7 @@ template <int W, bool TAG>
 __global__ __launch_bounds__(256) void k_expand_rc(const Key<W> *__restrict__ in, const uint32_t *__restrict__ cin,
                                                   uint64_t n, int k, Key<W> *__restrict__ out,
                                                   uint32_t *__restrict__ cout) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i >= n) return;
     Key<W> x = in[i];
     Key<W> y = kmer_rc<W>(x, k);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_expand_rc(const Key<W> *__restrict__ in
 template <int W>
 __global__ __launch_bounds__(256) void k_order_check(const Key<W> *__restrict__ keys, uint64_t n,
                                                     unsigned long long *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i + 1 >= n) return;
     const Key<W> a = key_load<W>(&keys[i]), b = key_load<W>(&keys[i + 1]);
     if (key_less_words<W>(b, a)) {
@@ -159,10 +159,10 @@ static void launch_expand(bbk_ctx *ctx, const void *in, const uint32_t *cin, uin
     if (n == 0) return;
     KernelTimer t(ctx, "expand", 3.0 * (double)n * sizeof(Key<W>));
     if (tag)
-        hipLaunchKernelGGL((k_expand_rc<W, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL((k_expand_rc<W, true>), bbk::grid_blocks((n + 255) / 256), dim3(256), 0, ctx->stream,
                            (const Key<W> *)in, cin, n, k, (Key<W> *)out, cout);
     else
-        hipLaunchKernelGGL((k_expand_rc<W, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL((k_expand_rc<W, false>), bbk::grid_blocks((n + 255) / 256), dim3(256), 0, ctx->stream,
                            (const Key<W> *)in, cin, n, k, (Key<W> *)out, cout);
     check_launch("k_expand_rc");
 }
@@ -204,7 +204,7 @@ void dedup_reads(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, bool with_mask, 
     }
     DevBuf koff((rd->n + 1) * sizeof(uint64_t));
     if (rd->n) {
-        hipLaunchKernelGGL(k_kmers_per_read, dim3((unsigned)((rd->n + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(k_kmers_per_read, bbk::grid_blocks((rd->n + 255) / 256), dim3(256), 0, ctx->stream,
                            rd->d_len, rd->n, k, koff.as<uint64_t>());
         check_launch("k_kmers_per_read");
     }
@@ -852,8 +852,7 @@ int bbk_kmerset_verify_order(bbk_ctx *ctx, const bbk_kmerset *s, uint64_t *n_run
         DevBuf d(8 * 40);
         BBK_HIP(hipMemsetAsync(d.p, 0, 8 * 40, ctx->stream));
         const uint64_t nblk = (s->n + 255) / 256;
-        BBK_REQUIRE(nblk < (1ull << 31), BBK_ERR_ARG, "set too large for one launch");
-        BBK_DISPATCH_W(s->W, hipLaunchKernelGGL((k_order_check<W_>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
+        BBK_DISPATCH_W(s->W, hipLaunchKernelGGL((k_order_check<W_>), bbk::grid_blocks(nblk), dim3(256), 0, ctx->stream,
                                                 (const Key<W_> *)s->keys.p, s->n,
                                                 (unsigned long long *)d.p));
         check_launch("k_order_check");

@@ -24,7 +24,7 @@ namespace bbk {
 
 // four masks per thread, one dword store (the array is padded to a multiple of 16 bytes)
 __global__ void k_u32_to_u8(const uint32_t *__restrict__ in, uint64_t n, uint8_t *__restrict__ out) {
-    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const uint64_t i = (BBK_GID()) * 4;
     if (i >= n) return;
     uint32_t w = 0;
 #pragma unroll
@@ -38,7 +38,7 @@ __global__ void k_u32_to_u8(const uint32_t *__restrict__ in, uint64_t n, uint8_t
 template <class IDX>
 __global__ void k_prefix_table(const uint64_t *__restrict__ keys, int W, uint64_t n, int shift, uint64_t nbins,
                                IDX *__restrict__ pref) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i >= n) return;
     const uint64_t t = keys[i * W] >> shift;
     const int64_t tp = (i == 0) ? -1 : (int64_t)(keys[(i - 1) * W] >> shift);
@@ -69,12 +69,11 @@ unsigned build_prefix_index(bbk_ctx *ctx, const uint64_t *keys, unsigned W, unsi
         BBK_HIP(hipMemsetAsync(prefix.p, 0, ((size_t)nbins + 1) * esz, ctx->stream));
     } else {
         const uint64_t nblk = (n + 255) / 256;
-        BBK_REQUIRE(nblk < (1ull << 31), BBK_ERR_ARG, "index of %llu k-mers exceeds the launch grid", (unsigned long long)n);
         if (*wide)
-            hipLaunchKernelGGL(k_prefix_table<uint64_t>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, keys, (int)W, n,
+            hipLaunchKernelGGL(k_prefix_table<uint64_t>, bbk::grid_blocks(nblk), dim3(256), 0, ctx->stream, keys, (int)W, n,
                                w0bits - bits, nbins, prefix.as<uint64_t>());
         else
-            hipLaunchKernelGGL(k_prefix_table<uint32_t>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, keys, (int)W, n,
+            hipLaunchKernelGGL(k_prefix_table<uint32_t>, bbk::grid_blocks(nblk), dim3(256), 0, ctx->stream, keys, (int)W, n,
                                w0bits - bits, nbins, prefix.as<uint32_t>());
         check_launch("k_prefix_table");
     }
@@ -109,9 +108,7 @@ static bbk_extindex *finish_extindex(Accum &acc) {
     x->masks.alloc(x->n + 16);
     if (x->n) {
         const uint64_t nblk = ((x->n + 3) / 4 + 255) / 256;
-        BBK_REQUIRE(nblk < (1ull << 31), BBK_ERR_ARG, "extension index of %llu k-mers exceeds the launch grid",
-                    (unsigned long long)x->n);
-        hipLaunchKernelGGL(k_u32_to_u8, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, m32.as<uint32_t>(), x->n,
+        hipLaunchKernelGGL(k_u32_to_u8, bbk::grid_blocks(nblk), dim3(256), 0, ctx->stream, m32.as<uint32_t>(), x->n,
                            x->masks.as<uint8_t>());
         check_launch("k_u32_to_u8");
     }
@@ -164,7 +161,7 @@ int bbk_extindex_from_device(bbk_ctx *ctx, const void *d_keys, const void *d_mas
 }
 
 __global__ void k_u8_to_u32(const uint8_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i < n) out[i] = in[i];
 }
 
@@ -176,7 +173,7 @@ int bbk_extindex_export_u32(bbk_ctx *ctx, const bbk_extindex *x, void *dst_keys,
         if (dst_keys) BBK_HIP(bbk::copy_async(dst_keys, x->keys.p, x->n * x->W * 8, hipMemcpyDefault, ctx->stream));
         if (dst_masks_u32) {
             DevBuf m(x->n * 4);
-            hipLaunchKernelGGL(k_u8_to_u32, dim3((unsigned)((x->n + 255) / 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_u8_to_u32, bbk::grid_blocks((x->n + 255) / 256), dim3(256), 0, ctx->stream,
                                x->masks.as<uint8_t>(), x->n, m.as<uint32_t>());
             check_launch("k_u8_to_u32");
             BBK_HIP(bbk::copy_async(dst_masks_u32, m.p, x->n * 4, hipMemcpyDefault, ctx->stream));

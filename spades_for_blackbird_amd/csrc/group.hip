@@ -393,6 +393,7 @@ int bbk_group_exchange_kmers(bbk_group *g, int rank, bbk_ctx *ctx, const bbk_kme
         // merge-unique of what the ranks sent (multiplicities are summed)
         const int rc = bbk_kmerset_from_device_ex(ctx, rk.p, with_vals ? rv.p : nullptr, n, local->k, flags, shard);
         if (rc != BBK_OK) throw Error{rc};
+        (*shard)->flags |= BBK_CANONICAL | (with_vals ? BBK_WITH_COUNTS : 0u) | (flags & BBK_UNSORTED);
     });
 }
 
@@ -447,7 +448,7 @@ int bbk_group_gather_kmers(bbk_group *g, int rank, bbk_ctx *ctx, const bbk_kmers
             bbk_kmerset *out = nullptr;
             const int rc = bbk_kmerset_from_device_ex(ctx, rk.p, rv.p, total, shard->k, 0, &out);  // ascending, counts summed
             if (rc != BBK_OK) throw Error{rc};
-            out->flags |= shard->flags & BBK_CANONICAL;
+            out->flags |= BBK_CANONICAL | BBK_WITH_COUNTS;
             *full = out;
         }
     });

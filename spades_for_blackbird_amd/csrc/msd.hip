@@ -219,7 +219,7 @@ __global__ void k_tile_reads(const uint64_t *__restrict__ coff, const uint64_t *
                              const uint32_t *__restrict__ len, uint64_t n_reads, uint64_t n_tiles, uint32_t tile,
                              uint32_t ch, uint32_t k, uint32_t max_reads, uint32_t max_words,
                              RdTile *__restrict__ out) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t t = BBK_GID();
     if (t >= n_tiles) return;
     const uint64_t c0 = t * (uint64_t)tile;
     const uint64_t r0 = read_at(coff, n_reads, c0), r1 = read_at(coff, n_reads, c0 + tile);
@@ -1765,7 +1765,7 @@ __global__ __launch_bounds__(256) void k_compact(const Key<W> *__restrict__ buf,
                                                 Key<W> *__restrict__ out, uint32_t *__restrict__ vout,
                                                 uint64_t mask0,  // cleared from word 0 (sort tag), else ~0
                                                 uint32_t slot_cap) {  // boff == null: bucket b starts at b*slot_cap
-    const uint32_t b = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t b = (uint32_t)((BBK_GID()) >> 6);
     if (b >= nbuckets) return;
     const int lane = threadIdx.x & 63;
     uint32_t c = dcount[b];
@@ -1806,12 +1806,12 @@ __global__ void k_iota_mul(uint32_t *__restrict__ out, uint32_t n, uint32_t mul)
 }
 
 __global__ void k_u32_to_u64(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out, uint32_t clampv) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i < n) out[i] = in[i] == 0xFFFFFFFFu ? (uint64_t)clampv : (uint64_t)in[i];
 }
 
 __global__ void k_scan_to_u32(const uint64_t *__restrict__ in, uint64_t n, uint64_t total, uint32_t *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i < n) out[i] = (uint32_t)in[i];
     if (i == n) out[n] = (uint32_t)total;
 }
@@ -1819,7 +1819,7 @@ __global__ void k_scan_to_u32(const uint64_t *__restrict__ in, uint64_t n, uint6
 // k-mers and chunks (of ch k-mer positions) of every read
 __global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, uint64_t n, uint32_t k, uint32_t ch,
                                   uint64_t *__restrict__ nk, uint64_t *__restrict__ nch) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i < n) {
         const uint32_t L = len[i];
         const uint64_t c = L >= k ? (uint64_t)(L - k + 1) : 0ull;
@@ -2565,7 +2565,7 @@ struct MsdRunner {
             DevBuf nk((rd->n + 1) * sizeof(uint64_t));
             coff.alloc((rd->n + 1) * sizeof(uint64_t));
             if (rd->n) {
-                hipLaunchKernelGGL(k_kmers_per_read2, dim3((unsigned)((rd->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(k_kmers_per_read2, bbk::grid_blocks((rd->n + 255) / 256), dim3(256), 0, ctx->stream,
                                    rd->d_len, rd->n, k, (uint32_t)RdCfg<W>::CH, nk.as<uint64_t>(), coff.as<uint64_t>());
                 check_launch("k_kmers_per_read2");
             }
@@ -3145,7 +3145,7 @@ struct MsdRunner {
                 auto put = [&](const void *ksrc, const uint32_t *vsrc, uint64_t first, uint64_t cnt, int seg = -1) {
                     if (!cnt) return;
                     if (seg >= 0) {
-                        hipLaunchKernelGGL(k_nw_widen, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                        hipLaunchKernelGGL(k_nw_widen, bbk::grid_blocks((cnt + 255) / 256), dim3(256), 0, ctx->stream,
                                            (const uint32_t *)ksrc + first, (uint32_t)cnt, (uint32_t)seg, nw_hb,
                                            ek.as<uint64_t>() + o);
                         check_launch("k_nw_widen");

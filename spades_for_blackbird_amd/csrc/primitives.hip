@@ -415,49 +415,9 @@ void pool_trim(int device) {
     pool().free_blocks.erase(it);
 }
 
-__global__ __launch_bounds__(256) void k_copy(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst,
-                                              size_t bytes, int vec16) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
-    size_t done = 0;
-    if (vec16) {
-        const size_t n16 = bytes >> 4;
-        const uint4 *s = reinterpret_cast<const uint4 *>(src);
-        uint4 *d = reinterpret_cast<uint4 *>(dst);
-        for (size_t j = i; j < n16; j += stride) d[j] = s[j];
-        done = n16 << 4;
-    }
-    for (size_t j = done + i; j < bytes; j += stride) dst[j] = src[j];
-}
-
-static bool is_device_memory(const void *p) {
-    if (pool_owns(p)) return true;
-    hipPointerAttribute_t at{};
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-        (void)hipGetLastError();  // plain host memory is not an error
-        return false;
-    }
-    return at.type == hipMemoryTypeDevice;
-}
-
 hipError_t copy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t stream) {
     if (bytes == 0) return hipSuccess;
-    const bool on_device = kind == hipMemcpyDeviceToDevice ||
-                           (kind == hipMemcpyDefault && is_device_memory(dst) && is_device_memory(src));
-    if (on_device && !getenv("BBK_RUNTIME_COPIES")) {  // BBK_RUNTIME_COPIES=1: A/B switch
-        const int vec16 = (((uintptr_t)dst | (uintptr_t)src) & 15u) == 0;
-        const size_t units = vec16 ? (bytes >> 4) + 1 : bytes;
-        const unsigned blocks = (unsigned)std::min<size_t>((units + 255) / 256, 16384);
-        hipLaunchKernelGGL(k_copy, dim3(blocks ? blocks : 1), dim3(256), 0, stream, (const unsigned char *)src,
-                           (unsigned char *)dst, bytes, vec16);
-        return hipGetLastError();
-    }
-    constexpr size_t kPiece = 1ull << 30;
-    for (size_t o = 0; o < bytes; o += kPiece) {
-        const size_t sz = bytes - o < kPiece ? bytes - o : kPiece;
-        const hipError_t e = hipMemcpyAsync((char *)dst + o, (const char *)src + o, sz, kind, stream);
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
+    return hipMemcpyAsync(dst, src, bytes, kind, stream);
 }
 
 void d2h_big(bbk_ctx *ctx, void *dst, const void *src, size_t bytes) {
@@ -1050,7 +1010,7 @@ __global__ __launch_bounds__(kThreads) void k_head_compact(const Key<W> *__restr
 __global__ __launch_bounds__(kThreads) void k_seg_reduce(const uint32_t *__restrict__ head_idx, uint64_t nseg,
                                                         const uint32_t *__restrict__ vals, int op,
                                                         uint32_t *__restrict__ out_vals) {
-    const uint64_t s = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    const uint64_t s = BBK_GID();
     if (s >= nseg) return;
     const uint32_t a = head_idx[s], b = head_idx[s + 1];
     uint32_t r;
@@ -1154,7 +1114,7 @@ static uint64_t unique_impl(bbk_ctx *ctx, const Key<W> *keys, const uint32_t *va
     BBK_HIP(hipMemcpyAsync(head.as<uint32_t>() + nd, &n32, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     if (dv) {
         KernelTimer t(ctx, "reduce", (double)nd * 8 + (vals ? (double)n * 4 : 0));
-        hipLaunchKernelGGL(k_seg_reduce, dim3((unsigned)((nd + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+        hipLaunchKernelGGL(k_seg_reduce, bbk::grid_blocks((nd + kThreads - 1) / kThreads), dim3(kThreads), 0,
                            ctx->stream, head.as<uint32_t>(), nd, vals, (int)op, dv);
         check_launch("k_seg_reduce");
     }

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_median_filter(const uint64_t *__restric
                                                       const Key<W> *__restrict__ keys, const uint32_t *__restrict__ counts,
                                                       PrefixTable P, uint32_t threshold,
                                                       uint8_t *__restrict__ keep) {
-    const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t r = (BBK_GID()) >> 6;
     if (r >= n_reads) return;
     const int lane = threadIdx.x & 63;
     const uint32_t L = len[r];
@@ -58,7 +58,7 @@ static void median_filter_impl(bbk_ctx *ctx, const bbk_reads *rd, const bbk_kmer
     const unsigned bits = build_prefix_index(ctx, s->keys.as<uint64_t>(), s->W, s->k, s->n, prefix, &wide);
     const int w0bits = (W == 1) ? (int)(2 * s->k) : 64;
     const uint64_t threads = rd->n * 64;
-    hipLaunchKernelGGL(k_median_filter<W>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, rd->d_words,
+    hipLaunchKernelGGL(k_median_filter<W>, bbk::grid_blocks((threads + 255) / 256), dim3(256), 0, ctx->stream, rd->d_words,
                        rd->d_woff, rd->d_len, rd->n, (int)s->k, s->keys.as<Key<W>>(), s->counts.as<uint32_t>(),
                        PrefixTable{prefix.p, w0bits - (int)bits, wide ? 1 : 0}, threshold, d_keep);
     check_launch("k_median_filter");

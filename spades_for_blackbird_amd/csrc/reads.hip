@@ -74,7 +74,7 @@ __device__ inline uint32_t genome_base(uint64_t seed, uint64_t g) {
 __global__ void k_synth_reads(uint64_t n_reads, uint32_t read_len, uint32_t words_per_read, uint64_t genome_len,
                               uint32_t sub_thresh, uint64_t seed_genome, uint64_t seed_reads,
                               uint64_t *__restrict__ words, uint64_t *__restrict__ woff, uint32_t *__restrict__ len) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = BBK_GID();
     const uint64_t r = gid / words_per_read;
     const uint32_t wj = (uint32_t)(gid % words_per_read);
     if (r >= n_reads) return;
@@ -108,7 +108,7 @@ __global__ void k_synth_meta(uint64_t n_reads, uint32_t read_len, uint32_t words
                              const uint64_t *__restrict__ cdf, const uint64_t *__restrict__ glen, uint32_t sub_thresh,
                              uint64_t seed_genome, uint64_t seed_reads, uint64_t *__restrict__ words,
                              uint64_t *__restrict__ woff, uint32_t *__restrict__ len) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = BBK_GID();
     const uint64_t r = gid / words_per_read;
     const uint32_t wj = (uint32_t)(gid % words_per_read);
     if (r >= n_reads) return;
@@ -144,12 +144,12 @@ __global__ void k_synth_meta(uint64_t n_reads, uint32_t read_len, uint32_t words
 }
 
 __global__ void k_len_to_words(const uint32_t *__restrict__ len, uint64_t n, uint64_t *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i < n) out[i] = ((uint64_t)len[i] + 31u) >> 5;
 }
 
 __global__ void k_len_to_u64(const uint32_t *__restrict__ len, uint64_t n, uint64_t *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i < n) out[i] = len[i];
 }
 
@@ -345,12 +345,12 @@ int bbk_reads_from_packed(bbk_ctx *ctx, const uint64_t *h_words, uint64_t n_word
         uint64_t total_words = 0, bases = 0;
         if (n_reads) {
             // word offsets and the base count come from the lengths, on the device (two scans)
-            hipLaunchKernelGGL(bbk::k_len_to_words, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(bbk::k_len_to_words, bbk::grid_blocks((n_reads + 255) / 256), dim3(256), 0, ctx->stream,
                                rd->own_len.as<uint32_t>(), n_reads, rd->own_woff.as<uint64_t>());
             bbk::check_launch("k_len_to_words");
             total_words = bbk::exclusive_scan_u64(ctx, rd->own_woff.as<uint64_t>(), rd->own_woff.as<uint64_t>(), n_reads);
             bbk::DevBuf bl((n_reads + 1) * sizeof(uint64_t));
-            hipLaunchKernelGGL(bbk::k_len_to_u64, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(bbk::k_len_to_u64, bbk::grid_blocks((n_reads + 255) / 256), dim3(256), 0, ctx->stream,
                                rd->own_len.as<uint32_t>(), n_reads, bl.as<uint64_t>());
             bbk::check_launch("k_len_to_u64");
             bases = bbk::exclusive_scan_u64(ctx, bl.as<uint64_t>(), bl.as<uint64_t>(), n_reads);
@@ -419,7 +419,7 @@ int bbk_reads_synth(bbk_ctx *ctx, uint64_t n_reads, uint32_t read_len, uint64_t 
         if (n_reads) {
             const uint64_t total = n_reads * wpr;
             const uint32_t thresh = (uint32_t)(sub_rate * 4294967296.0);
-            hipLaunchKernelGGL(bbk::k_synth_reads, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(bbk::k_synth_reads, bbk::grid_blocks((total + 255) / 256), dim3(256), 0, ctx->stream,
                                n_reads, read_len, wpr, genome_len, thresh, seed_genome, seed_reads,
                                rd->own_words.as<uint64_t>(), rd->own_woff.as<uint64_t>(), rd->own_len.as<uint32_t>());
             bbk::check_launch("k_synth_reads");
@@ -483,7 +483,7 @@ int bbk_reads_synth_meta(bbk_ctx *ctx, uint64_t n_reads, uint32_t read_len, uint
         if (n_reads) {
             const uint64_t total = n_reads * wpr;
             const uint32_t thresh = (uint32_t)(sub_rate * 4294967296.0);
-            hipLaunchKernelGGL(bbk::k_synth_meta, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, n_reads,
+            hipLaunchKernelGGL(bbk::k_synth_meta, bbk::grid_blocks((total + 255) / 256), dim3(256), 0, ctx->stream, n_reads,
                                read_len, wpr, n_genomes, d_cdf.as<uint64_t>(), d_glen.as<uint64_t>(), thresh, seed,
                                seed ^ 0xA5A5A5A5A5A5A5A5ull, rd->own_words.as<uint64_t>(), rd->own_woff.as<uint64_t>(),
                                rd->own_len.as<uint32_t>());
@@ -530,7 +530,7 @@ int bbk_reads_export_ascii(bbk_ctx *ctx, const bbk_reads *r, char *h_bases, uint
         h_offsets[0] = 0;
         if (n == 0) return;
         bbk::DevBuf boff((n + 1) * sizeof(uint64_t));
-        hipLaunchKernelGGL(bbk::k_len_to_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, r->d_len, n,
+        hipLaunchKernelGGL(bbk::k_len_to_u64, bbk::grid_blocks((n + 255) / 256), dim3(256), 0, ctx->stream, r->d_len, n,
                            boff.as<uint64_t>());
         bbk::check_launch("k_len_to_u64");
         const uint64_t total = bbk::exclusive_scan_u64(ctx, boff.as<uint64_t>(), boff.as<uint64_t>(), n);
@@ -540,7 +540,7 @@ int bbk_reads_export_ascii(bbk_ctx *ctx, const bbk_reads *r, char *h_bases, uint
             BBK_REQUIRE(total <= cap_bases, BBK_ERR_ARG, "bbk_reads_export_ascii: buffer too small (%llu needed)",
                         (unsigned long long)total);
             bbk::DevBuf out(total + 1);
-            hipLaunchKernelGGL(bbk::k_unpack_ascii, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, r->d_words,
+            hipLaunchKernelGGL(bbk::k_unpack_ascii, bbk::grid_blocks((n + 3) / 4), dim3(256), 0, ctx->stream, r->d_words,
                                r->d_woff, r->d_len, boff.as<uint64_t>(), n, out.as<char>());
             bbk::check_launch("k_unpack_ascii");
             BBK_HIP(hipMemcpyAsync(h_bases, out.p, total, hipMemcpyDeviceToHost, ctx->stream));

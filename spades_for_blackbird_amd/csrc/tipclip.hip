@@ -84,7 +84,7 @@ __device__ inline uint32_t tip_walk(const TipTable &T, Key<W> cur, uint32_t leng
 template <int W>
 __global__ __launch_bounds__(256) void k_tips_find(TipTable T, uint32_t length_bound, uint8_t *__restrict__ flag,
                                                   uint8_t *__restrict__ tipped, unsigned long long *__restrict__ removed) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t t = BBK_GID();
     if (t >= 2 * T.n) return;
     const uint64_t i = t >> 1;
     const bool rc_side = t & 1;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_tips_find(TipTable T, uint32_t length_b
 
 __global__ void k_tips_apply(const uint8_t *__restrict__ masks, const uint8_t *__restrict__ flag, uint64_t n,
                              uint8_t *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i < n) out[i] = flag[i] ? (uint8_t)0 : masks[i];  // IsolateVertex
 }
 
@@ -129,7 +129,7 @@ __global__ void k_tips_apply(const uint8_t *__restrict__ masks, const uint8_t *_
 template <int W>
 __global__ __launch_bounds__(256) void k_tips_links(TipTable T, const uint8_t *__restrict__ tipped,
                                                    uint8_t *__restrict__ out, unsigned long long *__restrict__ links) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i >= T.n) return;
     uint32_t stored = T.masks[i];
     if (tipped[2 * i] | tipped[2 * i + 1]) {
@@ -169,15 +169,15 @@ static void clip_tips_impl(bbk_ctx *ctx, bbk_extindex *x, uint32_t length_bound,
                (int)x->k, x->n};
     {
         KernelTimer t(ctx, "tip_find", 0.0);
-        hipLaunchKernelGGL(k_tips_find<W>, dim3((unsigned)((2 * x->n + 255) / 256)), dim3(256), 0, ctx->stream, T,
+        hipLaunchKernelGGL(k_tips_find<W>, bbk::grid_blocks((2 * x->n + 255) / 256), dim3(256), 0, ctx->stream, T,
                            length_bound, flag.as<uint8_t>(), tipped.as<uint8_t>(), ctr.as<unsigned long long>());
         check_launch("k_tips_find");
     }
-    hipLaunchKernelGGL(k_tips_apply, dim3((unsigned)((x->n + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(k_tips_apply, bbk::grid_blocks((x->n + 255) / 256), dim3(256), 0, ctx->stream,
                        x->masks.as<uint8_t>(), flag.as<uint8_t>(), x->n, m2.as<uint8_t>());
     check_launch("k_tips_apply");
     T.masks = m2.as<uint8_t>();
-    hipLaunchKernelGGL(k_tips_links<W>, dim3((unsigned)((x->n + 255) / 256)), dim3(256), 0, ctx->stream, T,
+    hipLaunchKernelGGL(k_tips_links<W>, bbk::grid_blocks((x->n + 255) / 256), dim3(256), 0, ctx->stream, T,
                        tipped.as<uint8_t>(), m3.as<uint8_t>(), ctr.as<unsigned long long>() + 1);
     check_launch("k_tips_links");
     unsigned long long h[2] = {0, 0};

@@ -51,7 +51,7 @@ __device__ __host__ inline bool mask_is_junction(uint32_t m) {
 }
 
 __global__ void k_count_starts(const uint8_t *__restrict__ masks, uint64_t n, uint64_t *__restrict__ cnt) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i >= n) return;
     const uint32_t m = masks[i];
     // outgoing edges of the k-mer and of its reverse complement (whose outgoing = this one's incoming)
@@ -62,7 +62,7 @@ __global__ void k_count_starts(const uint8_t *__restrict__ masks, uint64_t n, ui
 // outgoing edges for next = 0..3, then those of its reverse complement)
 __global__ void k_fill_starts(const uint8_t *__restrict__ masks, uint64_t n, const uint64_t *__restrict__ off,
                               uint64_t *__restrict__ starts) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i >= n) return;
     const uint32_t m = masks[i];
     if (!mask_is_junction(m)) return;
@@ -100,7 +100,7 @@ template <int W, int PASS>
 __global__ __launch_bounds__(256) void k_walk(const Key<W> *__restrict__ keys, const uint8_t *__restrict__ masks,
                                              PrefixTable P, uint64_t n, int k,
                                              const uint64_t *__restrict__ starts, uint64_t E, WalkOut o) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t e = BBK_GID();
     if (e >= E) return;
     if (PASS == 1 && o.keep[e] == 0) return;
     const uint64_t d = starts[e];
@@ -184,14 +184,14 @@ __global__ __launch_bounds__(256) void k_walk(const Key<W> *__restrict__ keys, c
 
 __global__ void k_loop_candidates(const uint8_t *__restrict__ masks, const uint8_t *__restrict__ visited, uint64_t n,
                                   uint64_t *__restrict__ flag) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i >= n) return;
     flag[i] = (!mask_is_junction(masks[i]) && !visited[i]) ? 1ull : 0ull;
 }
 
 __global__ void k_compact_candidates(const uint64_t *__restrict__ flag_scan, const uint8_t *__restrict__ masks,
                                      const uint8_t *__restrict__ visited, uint64_t n, uint64_t *__restrict__ idx) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i >= n) return;
     if (!mask_is_junction(masks[i]) && !visited[i]) idx[flag_scan[i]] = i;
 }
@@ -199,7 +199,7 @@ __global__ void k_compact_candidates(const uint64_t *__restrict__ flag_scan, con
 // unitigs -> packed reads (bbk_unitigs_to_reads): words per unitig, then one wavefront per unitig packs 32 bases per lane
 __global__ void k_unitig_words(const uint64_t *__restrict__ uoff, uint64_t nu, uint64_t *__restrict__ nw,
                                uint32_t *__restrict__ len, uint32_t *__restrict__ err) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i >= nu) return;
     const uint64_t l = uoff[i + 1] - uoff[i];
     if (l > 0xFFFFFFFFull) atomicOr(err, 1u);
@@ -209,7 +209,7 @@ __global__ void k_unitig_words(const uint64_t *__restrict__ uoff, uint64_t nu, u
 __global__ __launch_bounds__(256) void k_pack_unitigs(const char *__restrict__ bases, const uint64_t *__restrict__ uoff,
                                                      const uint64_t *__restrict__ woff, uint64_t nu,
                                                      uint64_t *__restrict__ words) {
-    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t i = (BBK_GID()) >> 6;
     if (i >= nu) return;
     const int lane = threadIdx.x & 63;
     const uint64_t b0 = uoff[i], len = uoff[i + 1] - b0, nw = (len + 31) >> 5;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_pack_unitigs(const char *__restrict__ b
 __global__ void k_gather_candidates(const uint64_t *__restrict__ keys, const uint8_t *__restrict__ masks,
                                     const uint64_t *__restrict__ idx, uint64_t nc, int W, uint64_t *__restrict__ out_keys,
                                     uint8_t *__restrict__ out_masks) {
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t c = BBK_GID();
     if (c >= nc) return;
     const uint64_t r = idx[c];
     for (int w = 0; w < W; ++w) out_keys[c * W + w] = keys[r * W + w];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_links(const uint64_t *__restrict__ key,
                                               uint64_t nrec, const uint8_t *__restrict__ selfconj,
                                               uint64_t *__restrict__ cnt, const uint64_t *__restrict__ off,
                                               uint64_t *__restrict__ links, unsigned long long *__restrict__ nvert) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = BBK_GID();
     if (r >= nrec) return;
     const uint64_t kr = key[r];
     const bool head = kr != ~0ull && (r == 0 || (key[r - 1] >> 2) != (kr >> 2));
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_links(const uint64_t *__restrict__ key,
 }
 
 __global__ void k_edge_ids(uint32_t *__restrict__ ids, uint64_t n2) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i < n2) ids[i] = (uint32_t)(i >> 1);
 }
 
@@ -355,10 +355,10 @@ static void run_walk(bbk_ctx *ctx, int pass, const bbk_extindex *x, const uint64
     // roofline claim); pass 1 also writes the bases
     KernelTimer t(ctx, pass == 0 ? "walk0" : "walk1", 2.0 * (double)x->n * (3.0 * x->W * 8 + 8 + 1));
     if (pass == 0)
-        hipLaunchKernelGGL((k_walk<W, 0>), dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL((k_walk<W, 0>), bbk::grid_blocks((E + 255) / 256), dim3(256), 0, ctx->stream,
                            x->keys.as<Key<W>>(), x->masks.as<uint8_t>(), P, x->n, (int)x->k, starts, E, o);
     else
-        hipLaunchKernelGGL((k_walk<W, 1>), dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL((k_walk<W, 1>), bbk::grid_blocks((E + 255) / 256), dim3(256), 0, ctx->stream,
                            x->keys.as<Key<W>>(), x->masks.as<uint8_t>(), P, x->n, (int)x->k, starts, E, o);
     check_launch("k_walk");
 }
@@ -418,7 +418,7 @@ __device__ inline void dev_put_dec(char *dst, uint64_t v, uint32_t len) {
 constexpr uint32_t kGfaTail = 15;  // "\tDP:f:0\tKC:i:0\n"
 
 __global__ void k_gfa_s_len(const uint64_t *__restrict__ uoff, uint64_t nu, uint64_t *__restrict__ len) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = BBK_GID();
     if (i < nu) len[i] = 2 + dev_dec_len(3 + 2 * i) + 1 + (uoff[i + 1] - uoff[i]) + kGfaTail;
 }
 
@@ -426,7 +426,7 @@ __global__ void k_gfa_s_len(const uint64_t *__restrict__ uoff, uint64_t nu, uint
 __global__ __launch_bounds__(256) void k_gfa_s_write(const char *__restrict__ bases, const uint64_t *__restrict__ uoff,
                                                     const uint64_t *__restrict__ pos, uint64_t nu,
                                                     char *__restrict__ out) {
-    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t i = (BBK_GID()) >> 6;
     if (i >= nu) return;
     const int lane = threadIdx.x & 63;
     char *d = out + pos[i];
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void k_gfa_s_write(const char *__restrict__ ba
 }
 
 __global__ void k_gfa_l_len(const uint64_t *__restrict__ links, uint64_t nl, uint32_t klen, uint64_t *__restrict__ len) {
-    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t l = BBK_GID();
     if (l < nl)
         len[l] = 2 + dev_dec_len(3 + 2 * (links[2 * l] >> 1)) + 3 + dev_dec_len(3 + 2 * (links[2 * l + 1] >> 1)) + 3 + klen + 2;
 }
@@ -453,7 +453,7 @@ __global__ void k_gfa_l_len(const uint64_t *__restrict__ links, uint64_t nl, uin
 // "L\t<e1>\t<+|->\t<e2>\t<+|->\t<k>M\n"
 __global__ void k_gfa_l_write(const uint64_t *__restrict__ links, const uint64_t *__restrict__ pos, uint64_t nl,
                               uint32_t k, uint32_t klen, char *__restrict__ out) {
-    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t l = BBK_GID();
     if (l >= nl) return;
     char *d = out + pos[l];
     const uint64_t a = links[2 * l], b = links[2 * l + 1];
@@ -491,12 +491,14 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
 
     // ---- start edges
     DevBuf cnt((n + 1) * 8);
-    hipLaunchKernelGGL(k_count_starts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(k_count_starts, bbk::grid_blocks((n + 255) / 256), dim3(256), 0, ctx->stream,
                        x->masks.as<uint8_t>(), n, cnt.as<uint64_t>());
     check_launch("k_count_starts");
     const uint64_t E = exclusive_scan_u64(ctx, cnt.as<uint64_t>(), cnt.as<uint64_t>(), n);
+    BBK_REQUIRE(E <= 8 * n, BBK_ERR_INTERNAL, "unitigs: %llu start edges counted for %llu k-mers", (unsigned long long)E,
+                (unsigned long long)n);
     DevBuf starts((E + 1) * 8);
-    hipLaunchKernelGGL(k_fill_starts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(k_fill_starts, bbk::grid_blocks((n + 255) / 256), dim3(256), 0, ctx->stream,
                        x->masks.as<uint8_t>(), n, cnt.as<uint64_t>(), starts.as<uint64_t>());
     check_launch("k_fill_starts");
     cnt.release();
@@ -511,12 +513,15 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     o.visited = visited.as<uint8_t>();
     o.err = err.as<uint32_t>();
     dispatch_walk(ctx, 0, x, starts.as<uint64_t>(), E, o);
+    uint32_t herr = 0;
+    d2h(ctx, &herr, err.p, 4);  // before the scans: a walk that gave up leaves its keep / length entries unwritten
+    BBK_REQUIRE(herr == 0, BBK_ERR_INTERNAL, "unitig walk failed (code %u): extension index is inconsistent", herr);
     DevBuf uid((E + 1) * 8), boff((E + 1) * 8);
     const uint64_t NU = exclusive_scan_u64(ctx, keep.as<uint64_t>(), uid.as<uint64_t>(), E);
     const uint64_t NB = exclusive_scan_u64(ctx, ulen.as<uint64_t>(), boff.as<uint64_t>(), E);
-    uint32_t herr = 0;
-    d2h(ctx, &herr, err.p, 4);
-    BBK_REQUIRE(herr == 0, BBK_ERR_INTERNAL, "unitig walk failed (code %u): extension index is inconsistent", herr);
+    BBK_REQUIRE(NU <= E && NB <= 2 * n + (uint64_t)(k + 1) * NU, BBK_ERR_INTERNAL,
+                "unitig walk: %llu unitigs / %llu bases from %llu start edges, %llu k-mers", (unsigned long long)NU,
+                (unsigned long long)NB, (unsigned long long)E, (unsigned long long)n);
     // edge ids travel as the u32 payload of the link-record sort, whose offsets are 32-bit: 2 NU < 2^32
     BBK_REQUIRE(NU < (1ull << 31), BBK_ERR_ARG, "%llu unitigs: the link-record sort takes 2^31 - 1 edges", (unsigned long long)NU);
 
@@ -542,7 +547,7 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
 
     // ---- loop candidates first: without perfect loops (the common case) links are made on the device
     DevBuf flag((n + 1) * 8);
-    hipLaunchKernelGGL(k_loop_candidates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(k_loop_candidates, bbk::grid_blocks((n + 255) / 256), dim3(256), 0, ctx->stream,
                        x->masks.as<uint8_t>(), visited.as<uint8_t>(), n, flag.as<uint64_t>());
     check_launch("k_loop_candidates");
     const uint64_t NC = exclusive_scan_u64(ctx, flag.as<uint64_t>(), flag.as<uint64_t>(), n);
@@ -558,7 +563,7 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
     std::vector<LinkRec> recs;
     if (NU) {
         DevBuf ids(2 * NU * 4 + 16), rtmp((2 * NU + 2) * 8), itmp(2 * NU * 4 + 16);
-        hipLaunchKernelGGL(k_edge_ids, dim3((unsigned)((2 * NU + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(k_edge_ids, bbk::grid_blocks((2 * NU + 255) / 256), dim3(256), 0, ctx->stream,
                            ids.as<uint32_t>(), 2 * NU);
         check_launch("k_edge_ids");
         int bits = 2;
@@ -573,13 +578,13 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
             KernelTimer t(ctx, "links", 0);
             DevBuf lcnt((2 * NU + 1) * 8), nv(16);
             BBK_HIP(hipMemsetAsync(nv.p, 0, 16, ctx->stream));
-            hipLaunchKernelGGL((k_links<false>), dim3((unsigned)((2 * NU + 255) / 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL((k_links<false>), bbk::grid_blocks((2 * NU + 255) / 256), dim3(256), 0, ctx->stream,
                                rec.as<uint64_t>(), ids.as<uint32_t>(), 2 * NU, selfc.as<uint8_t>(), lcnt.as<uint64_t>(),
                                (const uint64_t *)nullptr, (uint64_t *)nullptr, nv.as<unsigned long long>());
             check_launch("k_links<count>");
             const uint64_t NL = exclusive_scan_u64(ctx, lcnt.as<uint64_t>(), lcnt.as<uint64_t>(), 2 * NU);
             DevBuf dl(NL * 16 + 16);
-            hipLaunchKernelGGL((k_links<true>), dim3((unsigned)((2 * NU + 255) / 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL((k_links<true>), bbk::grid_blocks((2 * NU + 255) / 256), dim3(256), 0, ctx->stream,
                                rec.as<uint64_t>(), ids.as<uint32_t>(), 2 * NU, selfc.as<uint8_t>(), (uint64_t *)nullptr,
                                lcnt.as<uint64_t>(), dl.as<uint64_t>(), (unsigned long long *)nullptr);
             check_launch("k_links<write>");
@@ -619,7 +624,7 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
         T.W = (int)x->W;
         T.idx.resize(NC);
         DevBuf cidx(NC * 8 + 16);
-        hipLaunchKernelGGL(k_compact_candidates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(k_compact_candidates, bbk::grid_blocks((n + 255) / 256), dim3(256), 0, ctx->stream,
                            flag.as<uint64_t>(), x->masks.as<uint8_t>(), visited.as<uint8_t>(), n,
                            cidx.as<uint64_t>());
         check_launch("k_compact_candidates");
@@ -630,7 +635,7 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
         // gather the candidate rows on the device (they may lie anywhere in a table of billions of k-mers)
         {
             DevBuf gk(NC * T.W * 8 + 16), gm(NC + 16);
-            hipLaunchKernelGGL(k_gather_candidates, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_gather_candidates, bbk::grid_blocks((NC + 255) / 256), dim3(256), 0, ctx->stream,
                                x->keys.as<uint64_t>(), x->masks.as<uint8_t>(), cidx.as<uint64_t>(), NC, T.W,
                                gk.as<uint64_t>(), gm.as<uint8_t>());
             check_launch("k_gather_candidates");
@@ -761,7 +766,7 @@ __global__ __launch_bounds__(256) void k_unitig_kc(const char *__restrict__ base
                                                   uint64_t n_unitigs, int k1, const Key<W> *__restrict__ keys,
                                                   const uint32_t *__restrict__ counts, PrefixTable P,
                                                   uint64_t *__restrict__ kc, uint32_t *__restrict__ err) {
-    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t u = BBK_GID();
     if (u >= n_unitigs) return;
     const char *s = bases + off[u];
     const uint64_t len = off[u + 1] - off[u];
@@ -790,7 +795,7 @@ static void run_kc(bbk_ctx *ctx, const char *d_bases, const uint64_t *d_off, uin
                    const bbk_kmerset *set, const DevBuf &pref, unsigned pbits, bool wide, uint64_t *d_kc, uint32_t *d_err) {
     const int w0bits = (W == 1) ? (int)(2 * k1) : 64;
     KernelTimer t(ctx, "coverage", 0);
-    hipLaunchKernelGGL(k_unitig_kc<W>, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, ctx->stream, d_bases, d_off, nu,
+    hipLaunchKernelGGL(k_unitig_kc<W>, bbk::grid_blocks((nu + 255) / 256), dim3(256), 0, ctx->stream, d_bases, d_off, nu,
                        (int)k1, set->keys.as<Key<W>>(), set->counts.as<uint32_t>(),
                        PrefixTable{pref.p, w0bits - (int)pbits, wide ? 1 : 0}, d_kc, d_err);
     check_launch("k_unitig_kc");
@@ -890,7 +895,7 @@ int bbk_unitigs_to_reads(bbk_ctx *ctx, const bbk_unitigs *u, bbk_reads **out) {
         if (nu) {
             DevBuf err(16);
             BBK_HIP(hipMemsetAsync(err.p, 0, 16, ctx->stream));
-            hipLaunchKernelGGL(k_unitig_words, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, ctx->stream, d_uoff, nu,
+            hipLaunchKernelGGL(k_unitig_words, bbk::grid_blocks((nu + 255) / 256), dim3(256), 0, ctx->stream, d_uoff, nu,
                                rd->own_woff.as<uint64_t>(), rd->own_len.as<uint32_t>(), err.as<uint32_t>());
             check_launch("k_unitig_words");
             nwords = exclusive_scan_u64(ctx, rd->own_woff.as<uint64_t>(), rd->own_woff.as<uint64_t>(), nu);
@@ -902,7 +907,7 @@ int bbk_unitigs_to_reads(bbk_ctx *ctx, const bbk_unitigs *u, bbk_reads **out) {
         rd->n_words = nwords;
         rd->own_words.alloc((nwords + 1) * sizeof(uint64_t));
         if (nu) {
-            hipLaunchKernelGGL(k_pack_unitigs, dim3((unsigned)((nu * 64 + 255) / 256)), dim3(256), 0, ctx->stream, d_bases,
+            hipLaunchKernelGGL(k_pack_unitigs, bbk::grid_blocks((nu * 64 + 255) / 256), dim3(256), 0, ctx->stream, d_bases,
                                d_uoff, rd->own_woff.as<uint64_t>(), nu, rd->own_words.as<uint64_t>());
             check_launch("k_pack_unitigs");
         }
@@ -973,7 +978,7 @@ static void write_gfa_device(bbk_ctx *ctx, const bbk_unitigs *u, const char *pat
     DevBuf spos((nu + 1) * 8), lpos((nl + 1) * 8);
     uint64_t sbytes = 0, lbytes = 0;
     if (nu) {
-        hipLaunchKernelGGL(k_gfa_s_len, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(k_gfa_s_len, bbk::grid_blocks((nu + 255) / 256), dim3(256), 0, ctx->stream,
                            u->d_uoff.as<uint64_t>(), nu, spos.as<uint64_t>());
         check_launch("k_gfa_s_len");
         sbytes = exclusive_scan_u64(ctx, spos.as<uint64_t>(), spos.as<uint64_t>(), nu);
@@ -981,7 +986,7 @@ static void write_gfa_device(bbk_ctx *ctx, const bbk_unitigs *u, const char *pat
     uint32_t klen = 1;
     for (unsigned v = u->k; v >= 10; v /= 10) ++klen;
     if (nl) {
-        hipLaunchKernelGGL(k_gfa_l_len, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(k_gfa_l_len, bbk::grid_blocks((nl + 255) / 256), dim3(256), 0, ctx->stream,
                            u->d_links.as<uint64_t>(), nl, klen, lpos.as<uint64_t>());
         check_launch("k_gfa_l_len");
         lbytes = exclusive_scan_u64(ctx, lpos.as<uint64_t>(), lpos.as<uint64_t>(), nl);
@@ -991,13 +996,13 @@ static void write_gfa_device(bbk_ctx *ctx, const bbk_unitigs *u, const char *pat
     {
         KernelTimer t(ctx, "gfa_text", (double)total + (double)u->total_bases);
         if (nu) {
-            hipLaunchKernelGGL(k_gfa_s_write, dim3((unsigned)((nu * 64 + 255) / 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_gfa_s_write, bbk::grid_blocks((nu * 64 + 255) / 256), dim3(256), 0, ctx->stream,
                                u->d_bases.as<char>(), u->d_uoff.as<uint64_t>(), spos.as<uint64_t>(), nu,
                                text.as<char>());
             check_launch("k_gfa_s_write");
         }
         if (nl) {
-            hipLaunchKernelGGL(k_gfa_l_write, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_gfa_l_write, bbk::grid_blocks((nl + 255) / 256), dim3(256), 0, ctx->stream,
                                u->d_links.as<uint64_t>(), lpos.as<uint64_t>(), nl, (uint32_t)u->k, klen,
                                text.as<char>() + sbytes);
             check_launch("k_gfa_l_write");

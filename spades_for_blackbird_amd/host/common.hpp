@@ -65,13 +65,20 @@ inline double now_s() {
 struct Phases {
     double ctx = 0, parse = 0, upload = 0, device = 0, finish = 0, write = 0, total = 0, parse_wait = 0;
     uint64_t blocks = 0, fallback_blocks = 0;
+    // device memory the calling thread's allocator mapped and what mapping it cost (part of device_s / finish_s: ~30 ms
+    // per GiB when the driver has to clear the memory first, ~0.1 ms on memory nobody has used since boot)
+    double map_s = 0, mapped_gb = 0;
+    void memory(bbk_ctx *c) {
+        uint64_t total = 0;
+        if (c && bbk_ctx_memory_stats(c, nullptr, &total, &map_s, nullptr, nullptr) == BBK_OK) mapped_gb = (double)total / 1e9;
+    }
     void report(const char *tool) const {
         if (!getenv("BBK_PHASES")) return;
         printf("BBK_PHASES {\"tool\": \"%s\", \"ctx_s\": %.4f, \"parse_s\": %.4f, \"parse_wait_s\": %.4f, \"upload_s\": %.4f, "
                "\"device_s\": %.4f, \"finish_s\": %.4f, \"write_s\": %.4f, \"total_s\": %.4f, \"blocks\": %llu, "
-               "\"fallback_blocks\": %llu}\n",
+               "\"fallback_blocks\": %llu, \"memory_mapped_gb\": %.2f, \"memory_map_s\": %.4f}\n",
                tool, ctx, parse, parse_wait, upload, device, finish, write, total, (unsigned long long)blocks,
-               (unsigned long long)fallback_blocks);
+               (unsigned long long)fallback_blocks, mapped_gb, map_s);
         fflush(stdout);
     }
 };

@@ -205,6 +205,7 @@ int main(int argc, char **argv) {
     bbk_unitigs_free(u);
     bbk_extindex_free(ext);
     ph.total = now_s() - t_start;
+    ph.memory(ctx);
     ph.report("spades-gbuilder");
     info("SPAdes standalone graph builder finished");
     finish_process(ctx, 0);

@@ -157,6 +157,7 @@ int main(int argc, char **argv) {
     info("K-mer counting done, kmers saved to %s", out.c_str());
     bbk_kmerset_free(set);
     ph.total = now_s() - t_start;
+    ph.memory(ctx);
     ph.report("spades-kmercount");
     finish_process(ctx, 0);
 }
