@@ -240,6 +240,11 @@ void bbk_extindex_free(bbk_extindex *x);
  *      and FastGraphFromSequencesConstructor::ConstructGraph
  *      (common/assembly_graph/construction/debruijn_graph_constructor.hpp:182-388,390-518) ----- */
 int bbk_unitigs_build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs **out);
+/* ref_threads > 0: perfect loops are collected in the k-mer FILE order of a reference run with -t ref_threads (10 x t
+ * XXH3 buckets, ascending inside: kmer_extension_index_builder.hpp:73, CollectLoops debruijn_graph_constructor.hpp:308-344),
+ * which fixes where a loop string starts and which palindromic (k+1)-mer SplitLoop (:248-252) cuts a self-conjugate
+ * circle at -- the two things that depend on the thread count in the reference itself.  0 = ascending k-mer order. */
+int bbk_unitigs_build_ex(bbk_ctx *ctx, bbk_extindex *x, unsigned ref_threads, bbk_unitigs **out);
 /* `-c`: coverage of every condensed edge = sum over its (k+1)-mers of their multiplicity in
  * reads + rc(reads) (CoverageHashMapBuilder, common/utils/ph_map/coverage_hash_map_builder.hpp:15-54;
  * FillCoverageAndFlankingFromPHM, assembly_graph/graph_support/coverage_filling.hpp:44-62).  After this

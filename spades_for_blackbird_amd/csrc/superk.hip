@@ -65,18 +65,15 @@ constexpr int kSk2Tile = kSk2NT * kSk2Items;
 // Measured (10 M x 150 bp, k = 55, 11.8 ms): 2 ms of it without the lookups, 2 ms more with the k-mers prepared; the
 // rest is the table walk (slot -> record behind the entry -> compare).  Issuing the four lookups of a work item together
 // or walking them in lockstep was SLOWER (13.9 / 16.8 ms): the walk is bound by LDS accesses, not by their latency.
-// RTS: slots of the RECORD table (round 3).  At 50x coverage the reads that cover a stretch of the genome on the same
-// strand cut the SAME records out of it (a record's boundaries are minimizer positions: sequence, not read, decides
-// them; only the first and last record of a read and records with a sequencing error differ): about half of a bucket's
-// records are exact copies of one that is already in the KEEP area.  Such a record is recognised by comparing its RW
-// words (header included) with the kept one and dropped before any of its k-mers is cut out, canonicalised, hashed and
-// looked up.  Exact for the set and for the OR of edge masks (equal header = equal neighbours); multiplicities (OP 1)
-// would need every k-mer of the copy again and keep the old path.
+// Tried in round 3 and withdrawn: dropping a staged record that equals a kept one word for word before any of its
+// k-mers is touched (a 1024-slot record table beside the k-mer table).  Slower (9.8 -> 11.1 ms at k = 55, 13.0 -> 13.9
+// at k = 33): exact copies are rare, because records are cut at the boundaries of the read-relative segments of C
+// k-mers a lane of k_sk_part1 owns, not only at minimizer changes -- two reads over the same stretch cut it differently.
 struct SkdA {
-    static constexpr int NT = 256, TS = 2048, KEEP = 384, RTS = 1024;
+    static constexpr int NT = 256, TS = 2048, KEEP = 384;
 };
 struct SkdB {
-    static constexpr int NT = 512, TS = 8192, KEEP = 1024, RTS = 2048;  // 512 threads: 130 KB of LDS with 24-byte keys and 13 items per record
+    static constexpr int NT = 512, TS = 8192, KEEP = 1024;  // 512 threads: 130 KB of LDS with 24-byte keys and 13 items per record
 };
 constexpr uint32_t kSkdFailCap = 1u << 16;  // buckets the second chance takes
 constexpr uint32_t kSkdMaxProbes = 256;
@@ -193,7 +190,7 @@ __device__ inline uint64_t sk_read_at(const uint64_t *__restrict__ off, uint64_t
 
 __global__ void k_sk_segments(const uint32_t *__restrict__ len, uint64_t n, uint32_t k, uint32_t C,
                               uint64_t *__restrict__ nk, uint64_t *__restrict__ nseg) {
-    const uint64_t i = BBK_GID();
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const uint32_t L = len[i];
         const uint64_t c = L >= k ? (uint64_t)(L - k + 1) : 0ull;
@@ -204,7 +201,7 @@ __global__ void k_sk_segments(const uint32_t *__restrict__ len, uint64_t n, uint
 
 __global__ void k_sk_tiles(const uint64_t *__restrict__ coff, uint64_t n_reads, uint64_t n_tiles, uint32_t tile,
                            uint64_t n_segs, SkTile *__restrict__ out) {
-    const uint64_t t = BBK_GID();
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     const uint64_t c0 = t * (uint64_t)tile;
     const uint64_t c1 = (c0 + tile < n_segs ? c0 + tile : n_segs) - 1;
@@ -587,7 +584,7 @@ template <int W, int OP, class G>
 static size_t sk_dedup_smem(uint32_t C) {
     const uint32_t ipr = (C + kSkdSR - 1) / kSkdSR;
     return (size_t)(G::KEEP + G::NT) * (W + 1) * 8 + (size_t)(G::NT + 2) * 4 + (size_t)G::NT * 4 + (size_t)G::TS * 4 +
-           (OP ? (size_t)G::TS * 4 : 0) + 64 * 4 + (OP != 1 ? (size_t)G::RTS * 4 : 0) + (size_t)G::NT * ipr * 2 + 16;
+           (OP ? (size_t)G::TS * 4 : 0) + 64 * 4 + (size_t)G::NT * ipr * 2 + 16;
 }
 
 // The bucket is streamed in chunks of STG records through a staging area.  A lane takes a work item = up to 4
@@ -605,9 +602,8 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
                                                     const uint32_t *__restrict__ bucket_ids,
                                                     uint32_t *__restrict__ fail_list, uint32_t fail_ctr,
                                                     const uint8_t *__restrict__ hot) {
-    constexpr int RW = W + 1, NT = GEO::NT, TS = GEO::TS, KEEP = GEO::KEEP, STG = GEO::NT, SR = kSkdSR, RTS = GEO::RTS;
+    constexpr int RW = W + 1, NT = GEO::NT, TS = GEO::TS, KEEP = GEO::KEEP, STG = GEO::NT, SR = kSkdSR;
     constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-    constexpr bool RDEDUP = OP != 1;  // exact copies of kept records are dropped whole (see SkdA)
     static_assert(KEEP + STG <= 2048 && STG <= 4096, "entry / work item bit fields");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t *recs = reinterpret_cast<uint64_t *>(smem);                     // [KEEP + STG][RW]
@@ -616,8 +612,7 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
     uint32_t *table = newidx + STG;                                           // [TS]
     uint32_t *tvals = table + TS;                                             // [TS] (OP)
     uint32_t *tmp = tvals + (OP ? TS : 0);                                    // [64]
-    uint32_t *rtab = tmp + 64;                                                // [RTS] (RDEDUP): record index (KEEP area, then staging)
-    uint16_t *work = reinterpret_cast<uint16_t *>(rtab + (RDEDUP ? RTS : 0));  // [STG * ipr]: record << 5 | item of the record
+    uint16_t *work = reinterpret_cast<uint16_t *>(tmp + 64);                  // [STG * ipr]: record << 5 | item of the record
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = bucket_ids ? bucket_ids[blockIdx.x] : blockIdx.x;
     const unsigned long long r_begin = boff[b], r_end = boff[b + 1];
@@ -631,8 +626,6 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
         table[i] = EMPTY;
         if (OP) tvals[i] = 0;
     }
-    if (RDEDUP)
-        for (uint32_t i = tid; i < (uint32_t)RTS; i += NT) rtab[i] = EMPTY;
     uint32_t keep = 0;  // records in the KEEP area (uniform)
     bool failed = false;
     for (unsigned long long c0 = r_begin; c0 < r_end; c0 += STG) {
@@ -642,37 +635,8 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
         for (uint32_t i = tid; i < cnt * RW; i += NT) stg[i] = src[i];
         newidx[tid] = 0;
         __syncthreads();
-        bool copy = false;  // my staged record equals a kept (or earlier staged) one, word for word
-        if (RDEDUP && tid < cnt) {
-            const uint64_t *rp = stg + tid * RW;
-            uint32_t h = 0x9E3779B9u;
-#pragma unroll
-            for (int j = 0; j < RW; ++j) {
-                h = (h ^ (uint32_t)rp[j]) * 0x9E3779B1u;
-                h = (h ^ (uint32_t)(rp[j] >> 32)) * 0x85EBCA6Bu;
-                h ^= h >> 15;
-            }
-            uint32_t slot = h & (uint32_t)(RTS - 1);
-            const uint32_t me = (uint32_t)KEEP + tid;
-            for (uint32_t p = 0; p < (uint32_t)RTS; ++p) {
-                uint32_t e = rtab[slot];
-                if (e == EMPTY) {
-                    e = atomicCAS(&rtab[slot], EMPTY, me);
-                    if (e == EMPTY) break;  // first of its kind (so far)
-                }
-                const uint64_t *q = recs + e * RW;
-                bool same = true;
-#pragma unroll
-                for (int j = 0; j < RW; ++j) same = same && q[j] == rp[j];
-                if (same) {
-                    copy = true;
-                    break;
-                }
-                slot = (slot + 1u) & (uint32_t)(RTS - 1);
-            }
-        }
         {  // work items before every staged record
-            const uint32_t n = (tid < cnt && !copy) ? ((uint32_t)(stg[tid * RW + RW - 1] >> kSkHdrShift) & 63u) + 1u : 0u;
+            const uint32_t n = tid < cnt ? ((uint32_t)(stg[tid * RW + RW - 1] >> kSkHdrShift) & 63u) + 1u : 0u;
             const uint32_t items = (n + SR - 1) / SR;
             uint32_t incl = items;
 #pragma unroll
@@ -724,12 +688,13 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
                 const uint32_t entry = (tag << 18) | (((uint32_t)KEEP + r) << 7) | (j << 1) | strand;
                 uint32_t slot = h & (uint32_t)(TS - 1);
                 bool done = false;
-                // Two nested loops instead of one: the inner one only walks to the first slot that is empty or carries my
-                // tag (a load and two compares per step); what is expensive -- cutting the entry's k-mer out of its
-                // record and comparing 2W words -- happens in the outer loop, which nearly every lane leaves after ONE
-                // round (a 13-bit tag lets 1 in 8192 foreign entries through).  With the comparison inside a single
-                // probe loop every lane of the wave paid it once per step of the LONGEST chain among the 64 (3-4 steps
-                // at this load): ~250 vector instructions per k-mer for ~60 of straight-line code (SQ counters).
+                // Two nested loops: the inner one only walks to the first slot that is empty or carries my tag (a load
+                // and two compares per step); cutting the entry's k-mer out of its record and comparing 2W words happens
+                // in the outer loop, which nearly every lane leaves after one round (a 13-bit tag lets 1 in 8192 foreign
+                // entries through).  Worth 3 % (10.1 -> 9.8 ms at 10 M reads, k = 55), not the 40 % round 2 expected from
+                // "the divergent probe loop": the ISA of the loop body holds ~250 vector instructions per k-mer of
+                // STRAIGHT-LINE code (128-bit roll, base-order comparison, hash, two bit-field extractions) -- the
+                // instruction count measured with the SQ counters is the body, not the divergence.
                 for (uint32_t p = 0; p < kSkdMaxProbes && !done;) {
                     uint32_t e = table[slot];
                     while (e != EMPTY && (e >> 18) != tag && ++p < kSkdMaxProbes) {
@@ -805,24 +770,6 @@ __global__ __launch_bounds__(GEO::NT) void k_sk_dedup(const uint64_t *__restrict
             }
             keep += tot;
         }
-        if (RDEDUP && c0 + STG < r_end) {
-            // the next chunk is compared with what is in the KEEP area now: the table is rebuilt from it (the staged
-            // records it pointed at are gone; kept records are pairwise different, so no comparison is needed here)
-            for (uint32_t i = tid; i < (uint32_t)RTS; i += NT) rtab[i] = EMPTY;
-            __syncthreads();
-            for (uint32_t r = tid; r < keep; r += NT) {
-                const uint64_t *rp = recs + r * RW;
-                uint32_t h = 0x9E3779B9u;
-#pragma unroll
-                for (int j = 0; j < RW; ++j) {
-                    h = (h ^ (uint32_t)rp[j]) * 0x9E3779B1u;
-                    h = (h ^ (uint32_t)(rp[j] >> 32)) * 0x85EBCA6Bu;
-                    h ^= h >> 15;
-                }
-                uint32_t slot = h & (uint32_t)(RTS - 1);
-                while (atomicCAS(&rtab[slot], EMPTY, r) != EMPTY) slot = (slot + 1u) & (uint32_t)(RTS - 1);
-            }
-        }
         if (__syncthreads_or(failed)) {  // nothing of this bucket has been written
             if (tid == 0) sk_give_up(flags, fail_list, fail_ctr, b, (uint32_t)(r_end - r_begin));
             return;
@@ -887,7 +834,7 @@ __global__ __launch_bounds__(256) void k_sk_expand(const uint64_t *__restrict__ 
         r1 = boff[b + 1];
         stride = blockDim.x;
     } else {
-        r0 = BBK_GID();
+        r0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
         r1 = n_flat;
         stride = (unsigned long long)gridDim.x * blockDim.x;
     }
@@ -987,7 +934,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     const uint32_t C = std::min(w, n_cap);
 
     DevBuf nk((rd->n + 1) * sizeof(uint64_t)), coff((rd->n + 1) * sizeof(uint64_t));
-    hipLaunchKernelGGL(k_sk_segments, bbk::grid_blocks((rd->n + 255) / 256), dim3(256), 0, ctx->stream, rd->d_len, rd->n, k,
+    hipLaunchKernelGGL(k_sk_segments, dim3((unsigned)((rd->n + 255) / 256)), dim3(256), 0, ctx->stream, rd->d_len, rd->n, k,
                        C, nk.as<uint64_t>(), coff.as<uint64_t>());
     check_launch("k_sk_segments");
     const uint64_t N = exclusive_scan_u64(ctx, nk.as<uint64_t>(), nk.as<uint64_t>(), rd->n);
@@ -1063,7 +1010,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
                 k, m, w, C, (unsigned long long)n_segs, est_total, np, P1, P2, P.slot1, sm1, (double)N / (nb_plan * SkdA::TS));
 
     DevBuf tiles((size_t)(ntiles1 + 1) * sizeof(SkTile));
-    hipLaunchKernelGGL(k_sk_tiles, bbk::grid_blocks((ntiles1 + 255) / 256), dim3(256), 0, ctx->stream, coff.as<uint64_t>(),
+    hipLaunchKernelGGL(k_sk_tiles, dim3((unsigned)((ntiles1 + 255) / 256)), dim3(256), 0, ctx->stream, coff.as<uint64_t>(),
                        rd->n, ntiles1, (uint32_t)kSk1NT, n_segs, tiles.as<SkTile>());
     check_launch("k_sk_tiles");
     SkReads S{rd->d_words, rd->d_woff, rd->d_len, coff.as<uint64_t>(), tiles.as<SkTile>(), rd->n, n_segs};

@@ -236,6 +236,18 @@ __global__ void k_gather_candidates(const uint64_t *__restrict__ keys, const uin
     out_masks[c] = masks[r];
 }
 
+// XXH3 bucket (of nb) of every gathered candidate k-mer: the reference walks its k-mer file bucket by bucket
+// (KMerSegmentPolicy, utils/kmer_mph/kmer_buckets.hpp:28-33; 10 x threads buckets, kmer_extension_index_builder.hpp:73)
+template <int W>
+__global__ void k_candidate_buckets(const uint64_t *__restrict__ keys, uint64_t nc, uint64_t nb, uint32_t *__restrict__ out) {
+    const uint64_t c = BBK_GID();
+    if (c >= nc) return;
+    Key<W> q;
+#pragma unroll
+    for (int w = 0; w < W; ++w) q.w[w] = keys[c * W + w];
+    out[c] = (uint32_t)__umul64hi(xxh3_64<W>(q), nb);
+}
+
 // Links from the sorted link records (vertices = groups of equal canonical k-mer index): for every
 // canonical vertex every (incoming, outgoing) pair (GFAWriter::WriteLinks, io/graph/gfa_writer.cpp:43-52,
 // over the edge lists ConstructionHelper::LinkIncomingEdge/LinkOutgoingEdge build,
@@ -477,7 +489,7 @@ __global__ void k_gfa_l_write(const uint64_t *__restrict__ links, const uint64_t
     *d++ = '\n';
 }
 
-static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
+static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U, unsigned ref_threads) {
     const int k = (int)x->k;
     const uint64_t n = x->n;
     U.k = x->k;
@@ -632,6 +644,7 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
         T.keys.resize(NC * T.W);
         T.masks.resize(NC);
         T.used.assign(NC, 0);
+        std::vector<uint32_t> cand_bucket;
         // gather the candidate rows on the device (they may lie anywhere in a table of billions of k-mers)
         {
             DevBuf gk(NC * T.W * 8 + 16), gm(NC + 16);
@@ -641,7 +654,29 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
             check_launch("k_gather_candidates");
             d2h_big(ctx, T.keys.data(), gk.p, NC * T.W * 8);
             d2h_big(ctx, T.masks.data(), gm.p, NC);
+            // CollectLoops (:308-344) takes the first unvisited k-mer in K-MER FILE ORDER, and the file is the
+            // concatenation of 10 x threads XXH3 buckets, ascending inside: both the rotation of a loop string and the
+            // palindrome SplitLoop cuts a self-conjugate circle at follow from that order.  ref_threads = the -t of the
+            // reference run to reproduce (0: plain ascending order)
+            if (ref_threads) {
+                DevBuf gb(NC * 4 + 16);
+                const uint64_t nb = 10ull * ref_threads;
+                switch (T.W) {
+                    case 1: hipLaunchKernelGGL(k_candidate_buckets<1>, bbk::grid_blocks((NC + 255) / 256), dim3(256), 0, ctx->stream, gk.as<uint64_t>(), NC, nb, gb.as<uint32_t>()); break;
+                    case 2: hipLaunchKernelGGL(k_candidate_buckets<2>, bbk::grid_blocks((NC + 255) / 256), dim3(256), 0, ctx->stream, gk.as<uint64_t>(), NC, nb, gb.as<uint32_t>()); break;
+                    case 3: hipLaunchKernelGGL(k_candidate_buckets<3>, bbk::grid_blocks((NC + 255) / 256), dim3(256), 0, ctx->stream, gk.as<uint64_t>(), NC, nb, gb.as<uint32_t>()); break;
+                    default: hipLaunchKernelGGL(k_candidate_buckets<4>, bbk::grid_blocks((NC + 255) / 256), dim3(256), 0, ctx->stream, gk.as<uint64_t>(), NC, nb, gb.as<uint32_t>()); break;
+                }
+                check_launch("k_candidate_buckets");
+                cand_bucket.resize(NC);
+                d2h_big(ctx, cand_bucket.data(), gb.p, NC * 4);
+            }
         }
+        // visiting order of the candidates: ascending, or (bucket, ascending) = the reference's file order
+        std::vector<uint64_t> visit(NC);
+        for (uint64_t c = 0; c < NC; ++c) visit[c] = c;
+        if (!cand_bucket.empty())
+            std::stable_sort(visit.begin(), visit.end(), [&](uint64_t a, uint64_t b) { return cand_bucket[a] < cand_bucket[b]; });
         auto oriented_mask = [&](long pos, bool minimal) -> uint32_t {
             return minimal ? T.masks[(size_t)pos] : rev8(T.masks[(size_t)pos]);
         };
@@ -671,7 +706,8 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U) {
                 }
             ++n_loops;
         };
-        for (uint64_t c = 0; c < NC; ++c) {
+        for (uint64_t vi = 0; vi < NC; ++vi) {
+            const uint64_t c = visit[vi];
             if (T.used[c]) continue;
             // ConstructLoopFromVertex (:255-265) from the canonical k-mer
             const std::string x0 = unpack_kmer(&T.keys[c * T.W], k);
@@ -919,15 +955,18 @@ int bbk_unitigs_to_reads(bbk_ctx *ctx, const bbk_unitigs *u, bbk_reads **out) {
     });
 }
 
-int bbk_unitigs_build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs **out) {
+int bbk_unitigs_build_ex(bbk_ctx *ctx, bbk_extindex *x, unsigned ref_threads, bbk_unitigs **out) {
     return guarded([&] {
         BBK_REQUIRE(ctx && x && out, BBK_ERR_ARG, "bbk_unitigs_build: NULL argument");
+        BBK_REQUIRE(ref_threads <= (1u << 20), BBK_ERR_ARG, "bbk_unitigs_build_ex: ref_threads %u", ref_threads);
         BBK_HIP(hipSetDevice(ctx->device));
         auto u = std::make_unique<bbk_unitigs>();
-        build(ctx, x, *u);
+        build(ctx, x, *u, ref_threads);
         *out = u.release();
     });
 }
+
+int bbk_unitigs_build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs **out) { return bbk_unitigs_build_ex(ctx, x, 0, out); }
 
 uint64_t bbk_unitigs_count(const bbk_unitigs *u) { return u ? u->n : 0; }
 uint64_t bbk_unitigs_loops(const bbk_unitigs *u) { return u ? u->n_loops : 0; }

@@ -23,7 +23,7 @@ SYMBOLS = [
     "bbk_kmerset_instances", "bbk_kmerset_export", "bbk_kmerset_export_by_owner", "bbk_kmerset_free",
     "bbk_kmerset_write_final_kmers",
     "bbk_extindex_build", "bbk_extindex_size", "bbk_extindex_k", "bbk_extindex_export", "bbk_extindex_clip_tips", "bbk_extindex_free",
-    "bbk_unitigs_build", "bbk_unitigs_to_reads", "bbk_unitigs_add_coverage", "bbk_unitigs_add_coverage_counts", "bbk_unitigs_export_kc", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
+    "bbk_unitigs_build", "bbk_unitigs_build_ex", "bbk_unitigs_to_reads", "bbk_unitigs_add_coverage", "bbk_unitigs_add_coverage_counts", "bbk_unitigs_export_kc", "bbk_unitigs_count", "bbk_unitigs_loops", "bbk_unitigs_total_bases",
     "bbk_unitigs_vertices", "bbk_unitigs_links", "bbk_unitigs_export", "bbk_unitigs_export_links",
     "bbk_unitigs_write_gfa", "bbk_unitigs_write_fasta", "bbk_unitigs_write_fastg", "bbk_unitigs_write_spades", "bbk_unitigs_free",
     "bbk_group_create", "bbk_group_size", "bbk_group_device", "bbk_group_destroy", "bbk_group_abort", "bbk_group_exchange_kmers",
@@ -147,6 +147,7 @@ def load_library():
         L.bbk_extindex_free.argtypes = [vp]
     if hasattr(L, "bbk_unitigs_build"):
         L.bbk_unitigs_build.argtypes = [vp, vp, C.POINTER(vp)]
+        L.bbk_unitigs_build_ex.argtypes = [vp, vp, C.c_uint, C.POINTER(vp)]
         L.bbk_unitigs_to_reads.argtypes = [vp, vp, C.POINTER(vp)]
         for f in ("count", "loops", "total_bases", "vertices", "links"):
             getattr(L, "bbk_unitigs_" + f).restype = u64
@@ -349,10 +350,11 @@ class Context:
         _check(self._L.bbk_extindex_from_device(self._h, _ptr(d_keys), _ptr(d_masks_u32), n, k, C.byref(h)))
         return ExtIndex(self, h)
 
-    def unitigs(self, ext):
-        """UnbranchingPathExtractor + FastGraphFromSequencesConstructor analogue."""
+    def unitigs(self, ext, ref_threads=0):
+        """UnbranchingPathExtractor + FastGraphFromSequencesConstructor analogue.  ref_threads > 0: perfect loops are
+        collected in the k-mer file order of a reference run with that -t (loop rotation, SplitLoop choice)."""
         h = C.c_void_p()
-        _check(self._L.bbk_unitigs_build(self._h, ext._h, C.byref(h)))
+        _check(self._L.bbk_unitigs_build_ex(self._h, ext._h, ref_threads, C.byref(h)))
         return Unitigs(self, h)
 
     def close(self):

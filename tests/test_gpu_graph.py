@@ -110,6 +110,30 @@ def test_loop_and_self_rc_goldens(ctx, golden, tmp_path):
     assert sorted(u.sequences()) == sorted(g["S"])
 
 
+def test_loops_in_reference_file_order(ctx, golden, tmp_path):
+    """End-to-end pin of CollectLoops / SplitLoop (debruijn_graph_constructor.hpp:248-265,308-344): with
+    bbk_unitigs_build_ex(ref_threads = T) the engine visits the leftover k-mers in the k-mer file order of a reference
+    run with -t T (10 T XXH3 buckets, ascending inside), like the oracle (which reproduces the recorded reference
+    output of the SplitLoop golden string for string, tests/test_oracle_golden.py::test_split_loop_golden): the loop
+    strings -- where they start, and which palindromic (k+1)-mer a self-conjugate circle is cut at -- are then EQUAL,
+    not only equal modulo rotation."""
+    cases = [golden["split_loop_k5"]["reads"], golden["loop_k5"]["reads"],
+             ["TTTCCTCATGCAATATTGCATGAGGAAA" + "TTTCCTCATGCAAT", "CTTGCTGTGTCCACCCCATCGGAC" * 2, "GGATTACAGGCATGAGCCACC" * 2]]
+    for reads in cases:
+        for T in (1, 2, 5):
+            r = ctx.reads_from_ascii(reads)
+            u = ctx.unitigs(ctx.extindex(r, 5), ref_threads=T)
+            ou = O.ExtIndex(reads, 5, T).unitigs()
+            got, exp = u.sequences(), ou.seqs
+            assert u.n_loops == ou.n_loops and u.n_loops > 0
+            nl = u.n_loops
+            assert got[len(got) - nl:] == exp[len(exp) - nl:], (reads, T)      # the loop strings, in order
+            assert sorted(got[:len(got) - nl]) == sorted(exp[:len(exp) - nl])  # the paths (their order differs by design)
+    g = golden["split_loop_k5"]
+    u = ctx.unitigs(ctx.extindex(ctx.reads_from_ascii(g["reads"]), g["k"]), ref_threads=1)
+    assert u.sequences() == g["S"]  # the recorded reference output itself
+
+
 @pytest.mark.parametrize("k,seed", [(5, 1), (9, 2), (21, 3), (21, 4), (33, 5), (55, 6), (77, 7)])
 def test_gfa_vs_oracle_synthetic(ctx, k, seed, tmp_path):
     reads = synth_reads(1500, read_len=100, genome_len=4000 if k > 9 else 600, sub_rate=0.01, seed=seed,

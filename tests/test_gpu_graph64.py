@@ -106,6 +106,7 @@ def _graph64():
     assert len(ur) == nu and ur.bases == nb
     cu = ctx.count(ur, K + 1, B.CANONICAL | B.WITH_COUNTS)
     assert cu.instances == n_e + excess and len(cu) == n_e, (cu.instances, len(cu), n_e)
+    ctx.trim()  # the engine's free working memory goes back to the driver: torch needs 60 GB for the export below
     ck = torch.empty((n_e, 1), dtype=torch.int64, device="cuda")
     cc = torch.empty(n_e, dtype=torch.int32, device="cuda")
     cu.export_to(ck, B.ORDER_SORTED, dst_counts=cc)
