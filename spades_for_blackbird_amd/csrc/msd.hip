@@ -2336,7 +2336,7 @@ static size_t bucket_hash32_smem() {
 
 // 4-byte records of one segment -> 8-byte keys (overflowing slots are reprocessed by the exact path on a key array)
 __global__ void k_nw_widen(const uint32_t *__restrict__ in, uint32_t n, uint32_t seg, int hb, uint64_t *__restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = (uint32_t)BBK_GID();  // cnt is a 32-bit count
     if (i < n) out[i] = nw_key(seg, in[i], hb);
 }
 

@@ -156,7 +156,7 @@ __global__ void k_len_to_u64(const uint32_t *__restrict__ len, uint64_t n, uint6
 __global__ void k_unpack_ascii(const uint64_t *__restrict__ words, const uint64_t *__restrict__ woff,
                                const uint32_t *__restrict__ len, const uint64_t *__restrict__ boff, uint64_t n_reads,
                                char *__restrict__ out) {
-    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    const uint64_t r = BBK_GID() >> 6;  // one wavefront per read
     if (r >= n_reads) return;
     const int lane = threadIdx.x & 63;
     const uint64_t *rw = words + woff[r];
