@@ -922,8 +922,16 @@ int bbk_kmerset_write_final_kmers(bbk_ctx *ctx, const bbk_kmerset *s, const char
         }
         const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
         BBK_REQUIRE(fd >= 0, BBK_ERR_IO, "cannot open %s for writing", path);
-        const bool ok = d2f_big(ctx, fd, 0, src, s->n * rec);
+        bool ok = false;
+        try {
+            ok = d2f_big(ctx, fd, 0, src, s->n * rec);
+        } catch (...) {  // a HIP error inside the stream: no descriptor and no full-size, half-written file is left behind
+            (void)close(fd);
+            (void)unlink(path);
+            throw;
+        }
         const int cl = close(fd);
+        if (!(ok && cl == 0)) (void)unlink(path);
         BBK_REQUIRE(ok && cl == 0, BBK_ERR_IO, "short write to %s", path);
     });
 }

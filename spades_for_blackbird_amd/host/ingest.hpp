@@ -455,9 +455,21 @@ class Ingest {
                     const int want = (int)std::min<size_t>(cur_block_ - fill_, 1u << 30);
                     const int got = gzread(gz_, &buf_[fill_], (unsigned)want);
                     if (got <= 0) {
+                        // got < 0: corrupt or truncated .gz.  kseq ends the stream there without a word (its reader
+                        // returns -1 and kseq_read reports end of file, ext/include/kseq/kseq.h:95-110): the records read
+                        // so far are kept, like the reference -- but not silently
+                        if (got < 0) {
+                            int en = 0;
+                            const char *msg = gzerror(gz_, &en);
+                            fprintf(stderr, "WARNING: %s: gzip stream error (%s): the input ends here, %llu bytes into the "
+                                            "decompressed data\n",
+                                    current_file().c_str(), msg ? msg : "?",
+                                    (unsigned long long)gz_bytes_);
+                        }
                         gz_eof_ = true;
                         break;
                     }
+                    gz_bytes_ += (uint64_t)got;
                     fill_ += (size_t)got;
                 }
                 const bool final = gz_eof_;
@@ -523,6 +535,7 @@ class Ingest {
             }
             gzbuffer(gz_, 1u << 20);
             gz_eof_ = false;
+            gz_bytes_ = 0;
             fill_ = 0;
         }
         open_ = true;
@@ -547,6 +560,7 @@ class Ingest {
     size_t size_ = 0, off_ = 0;
     gzFile gz_ = nullptr;
     bool gz_eof_ = false;
+    uint64_t gz_bytes_ = 0;  // decompressed bytes of the current file (for the message on a corrupt stream)
     std::string buf_;
     size_t fill_ = 0;
     uint64_t total_reads_ = 0, fallbacks_ = 0;
