@@ -104,7 +104,9 @@ int current_device() {
 std::unique_ptr<Arena> arena_reserve() {
     auto A = std::make_unique<Arena>();
     const char *e = getenv("BBK_ARENA_VA_GB");
-    const size_t first = e ? (size_t)strtoull(e, nullptr, 10) << 30 : (16ull << 40);
+    // 4 TiB: hundreds of trim cycles of a 288 GB device before a new generation is needed, and eight rank threads of one
+    // process (spades-kmercount --devices) together stay far below the 128 TiB of user address space
+    const size_t first = e ? (size_t)strtoull(e, nullptr, 10) << 30 : (4ull << 40);
     for (size_t sz = first; sz >= (e ? first : (1ull << 38)); sz >>= 1) {
         void *p = nullptr;
         if (hipMemAddressReserve(&p, sz, 0, nullptr, 0) == hipSuccess && p) {

@@ -59,6 +59,26 @@ def _exchange_counts(send_counts, dev, group):
     return [int(x) for x in rc.tolist()], int(mx.item())
 
 
+def ensure_headroom(ctx, need_bytes, what=""):
+    """The engine's arena keeps the device memory of its last calls mapped (that is what makes the next call fast);
+    torch allocates the exchange buffers beside it.  Before a large torch allocation: if the driver's free memory does
+    not cover it with 10 % to spare, the arena's free chunks are handed back (bbk_ctx_trim; re-mapping them later costs
+    up to 30 ms/GiB, so this is not done unconditionally); if it still does not fit, say so instead of dying in the
+    allocator."""
+    import torch
+    free, total = torch.cuda.mem_get_info(ctx.device)
+    if free < need_bytes * 1.1:
+        ctx.trim()
+        torch.cuda.empty_cache()
+        free, total = torch.cuda.mem_get_info(ctx.device)
+        if free < need_bytes:
+            st = ctx.memory_stats()
+            raise MemoryError("rank needs %.1f GB for %s but the device has %.1f GB free (%.1f GB mapped by the engine's "
+                              "arena after a trim, %.1f GB reserved by torch)"
+                              % (need_bytes / 1e9, what or "the exchange", free / 1e9, st["mapped_now"] / 1e9,
+                                 torch.cuda.memory_reserved(ctx.device) / 1e9))
+
+
 def exchange_by_owner(send, send_counts, words, group=None, payload=None, max_msg_bytes=None):
     """send: int64 tensor [n, words] grouped by owner; send_counts: per-owner record counts; payload: optional int32
     tensor [n] that travels with the records (multiplicities or mask bits).
@@ -131,6 +151,8 @@ def sharded_count(ctx, reads, k, both_strands=True, group=None, reference_order=
     dev = torch.device("cuda", ctx.device)
     # local dedup only (hash-bucket order): the owner partition does not need sorted input
     c = ctx.count(reads, k, E.CANONICAL | E.UNSORTED)
+    # send + receive buffers (the shard is about as large as the local set) + the merge's working space
+    ensure_headroom(ctx, 3 * len(c) * nw * 8, "the k-mer exchange")
     send = torch.empty((len(c), nw), dtype=torch.int64, device=dev)
     counts = c.export_by_owner(world, dst_keys=send)
     c.free()
@@ -158,6 +180,7 @@ def sharded_extindex(ctx, reads, k, group=None):
     nw = E.words(k)
     dev = torch.device("cuda", ctx.device)
     c = ctx.count(reads, k, E.CANONICAL | E.UNSORTED | E.WITH_MASKS)
+    ensure_headroom(ctx, 3 * len(c) * (nw * 8 + 4), "the extension-index exchange")
     send = torch.empty((len(c), nw), dtype=torch.int64, device=dev)
     pay = torch.empty(len(c), dtype=torch.int32, device=dev)
     counts = c.export_by_owner(world, dst_keys=send, dst_counts=pay)
