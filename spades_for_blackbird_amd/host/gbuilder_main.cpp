@@ -107,10 +107,8 @@ int main(int argc, char **argv) {
     if (!devices.empty()) {
         // ---- several devices: every rank reduces its blocks to (canonical k-mer, OR of mask bits) records, the records go
         //      to the k-mer's owner in one all-to-all, the owners' shards are gathered on rank 0 for the walk
-        bbk_group *g = nullptr;
-        check(bbk_group_create(devices.data(), (int)devices.size(), exchange_arg == "rccl" ? BBK_EXCHANGE_RCCL : BBK_EXCHANGE_COPY, &g),
-              "bbk_group_create");
-        const int n = bbk_group_size(g);
+        auto gf = create_group_async(devices, exchange_arg == "rccl" ? BBK_EXCHANGE_RCCL : BBK_EXCHANGE_COPY);
+        const int n = (int)devices.size();
         info("Using %d device(s), %s exchange", n, exchange_arg.c_str());
         std::vector<bbk_counter *> xc((size_t)n, nullptr), cc((size_t)n, nullptr);
         std::vector<bbk_ctx *> ctxs;
@@ -127,22 +125,22 @@ int main(int argc, char **argv) {
             bbk_kmerset *local = nullptr;
             bbk_extindex *shard = nullptr, *full = nullptr;
             check(bbk_count_finish(xc[(size_t)r], &local), "bbk_count_finish");
-            check(bbk_group_exchange_extindex(g, r, c, local, &shard), "bbk_group_exchange_extindex");
+            check(bbk_group_exchange_extindex(gf.get(), r, c, local, &shard), "bbk_group_exchange_extindex");
             bbk_kmerset_free(local);
-            check(bbk_group_gather_extindex(g, r, c, shard, 0, &full), "bbk_group_gather_extindex");
+            check(bbk_group_gather_extindex(gf.get(), r, c, shard, 0, &full), "bbk_group_gather_extindex");
             bbk_extindex_free(shard);
             if (r == 0) ext = full;
             if (want_cov) {
                 bbk_kmerset *lc = nullptr, *sc = nullptr, *fc = nullptr;
                 check(bbk_count_finish(cc[(size_t)r], &lc), "bbk_count_finish");
-                check(bbk_group_exchange_kmers(g, r, c, lc, BBK_UNSORTED, &sc), "bbk_group_exchange_kmers");
+                check(bbk_group_exchange_kmers(gf.get(), r, c, lc, BBK_UNSORTED, &sc), "bbk_group_exchange_kmers");
                 bbk_kmerset_free(lc);
-                check(bbk_group_gather_kmers(g, r, c, sc, 0, &fc), "bbk_group_gather_kmers");
+                check(bbk_group_gather_kmers(gf.get(), r, c, sc, 0, &fc), "bbk_group_gather_kmers");
                 bbk_kmerset_free(sc);
                 if (r == 0) kp1 = fc;
             }
         };
-        const uint64_t n_reads = run_ranks(g, files, (size_t)bufsize, threads ? (int)threads : default_threads(), ph, hooks, ctxs);
+        const uint64_t n_reads = run_ranks(devices, files, (size_t)bufsize, threads ? (int)threads : default_threads(), ph, hooks, ctxs);
         info("Used %llu reads", (unsigned long long)n_reads);
         ctx = ctxs[0];
         t0 = now_s();

@@ -89,10 +89,8 @@ int main(int argc, char **argv) {
     if (!devices.empty()) {
         // ---- several devices (or one, through the same code): local count -> owner exchange -> per-rank final_kmers order
         //      -> one file.  The group (RCCL communicators) is set up while the parser reads the first block.
-        bbk_group *g = nullptr;
-        check(bbk_group_create(devices.data(), (int)devices.size(), exchange_arg == "rccl" ? BBK_EXCHANGE_RCCL : BBK_EXCHANGE_COPY, &g),
-              "bbk_group_create");
-        const int n = bbk_group_size(g);
+        auto gf = create_group_async(devices, exchange_arg == "rccl" ? BBK_EXCHANGE_RCCL : BBK_EXCHANGE_COPY);
+        const int n = (int)devices.size();
         info("Using %d device(s), %s exchange", n, exchange_arg.c_str());
         const unsigned W = bbk_words(K);
         std::vector<bbk_counter *> counters((size_t)n, nullptr);
@@ -106,7 +104,7 @@ int main(int argc, char **argv) {
         hooks.finish = [&](int r, bbk_ctx *c) {
             bbk_kmerset *local = nullptr, *shard = nullptr, *both = nullptr;
             check(bbk_count_finish(counters[(size_t)r], &local), "bbk_count_finish");
-            check(bbk_group_exchange_kmers(g, r, c, local, BBK_UNSORTED, &shard), "bbk_group_exchange_kmers");
+            check(bbk_group_exchange_kmers(gf.get(), r, c, local, BBK_UNSORTED, &shard), "bbk_group_exchange_kmers");
             bbk_kmerset_free(local);
             // a k-mer and its reverse complement share the canonical owner: the shard expands on its own
             check(bbk_kmerset_both_strands_ex(c, shard, BBK_REFERENCE_ORDER, &both), "bbk_kmerset_both_strands_ex");
@@ -117,7 +115,7 @@ int main(int argc, char **argv) {
             check(bbk_kmerset_export(c, both, BBK_ORDER_REFERENCE_BUCKETS16, sh.keys.data(), nullptr), "bbk_kmerset_export");
             bbk_kmerset_free(both);
         };
-        run_ranks(g, files, (size_t)bufsize, threads ? (int)threads : default_threads(), ph, hooks, ctxs);
+        run_ranks(devices, files, (size_t)bufsize, threads ? (int)threads : default_threads(), ph, hooks, ctxs);
         if (!workdir.empty()) mkdir(workdir.c_str(), 0755);
         const std::string out = (workdir.empty() ? std::string("") : workdir + "/") + "final_kmers";
         const double t0w = now_s();

@@ -10,6 +10,7 @@
 
 #include <atomic>
 #include <deque>
+#include <future>
 
 #include "common.hpp"
 
@@ -29,6 +30,20 @@ inline bool parse_devices(const std::string &arg, std::vector<int> &out) {
     return !out.empty();
 }
 
+// The group (RCCL: loading librccl and ncclCommInitAll take seconds) is set up on a thread of its own while the ranks
+// parse and count; the first collective call waits for it.
+inline std::shared_future<bbk_group *> create_group_async(const std::vector<int> &devices, unsigned exchange) {
+    return std::async(std::launch::async, [devices, exchange] {
+               bbk_group *g = nullptr;
+               const double t0 = now_s();
+               check(bbk_group_create(devices.data(), (int)devices.size(), exchange, &g), "bbk_group_create");
+               info("Device group ready (%d device(s), %s exchange, %.2f s)", (int)devices.size(),
+                    exchange == BBK_EXCHANGE_RCCL ? "RCCL" : "peer-copy", now_s() - t0);
+               return g;
+           })
+        .share();
+}
+
 struct RankHooks {
     std::function<void(int rank, bbk_ctx *ctx)> init;                      // accumulators of the rank
     std::function<void(int rank, bbk_ctx *ctx, bbk_reads *r)> push;        // one uploaded block
@@ -38,9 +53,9 @@ struct RankHooks {
 // Runs the ranks to completion; returns the number of reads.  ctxs[rank] receives the rank's context (left alive: the
 // caller's writer may still need the results that live on it).  Any failure ends the process (fatal), like the single-
 // device path.
-inline uint64_t run_ranks(bbk_group *g, const std::vector<std::string> &files, size_t block_bytes, int threads, Phases &ph,
-                          const RankHooks &hooks, std::vector<bbk_ctx *> &ctxs) {
-    const int n = bbk_group_size(g);
+inline uint64_t run_ranks(const std::vector<int> &devices, const std::vector<std::string> &files, size_t block_bytes, int threads,
+                          Phases &ph, const RankHooks &hooks, std::vector<bbk_ctx *> &ctxs) {
+    const int n = (int)devices.size();
     ctxs.assign((size_t)n, nullptr);
     Ingest ing(files, block_bytes, threads);
     ing.on_file = [](const std::string &f) { info("Processing %s", f.c_str()); };
@@ -80,7 +95,7 @@ inline uint64_t run_ranks(bbk_group *g, const std::vector<std::string> &files, s
     for (int r = 0; r < n; ++r)
         ranks.emplace_back([&, r] {
             const double t0c = now_s();
-            check(bbk_ctx_create(bbk_group_device(g, r), &ctxs[(size_t)r]), "bbk_ctx_create");
+            check(bbk_ctx_create(devices[(size_t)r], &ctxs[(size_t)r]), "bbk_ctx_create");
             ctx_s[(size_t)r] = now_s() - t0c;
             bbk_ctx *ctx = ctxs[(size_t)r];
             if (hooks.init) hooks.init(r, ctx);
