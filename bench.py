@@ -177,10 +177,13 @@ def write_fasta(reads, path, n=None):
     return nr
 
 
-def run_cli(cmd):
+def run_cli(cmd, timeout=None):
     env = dict(os.environ, BBK_PHASES="1")
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %s s" % timeout, "wall_s": time.perf_counter() - t0}
     wall = time.perf_counter() - t0
     if r.returncode != 0:
         return {"error": (r.stderr or r.stdout)[-400:], "wall_s": wall}
@@ -189,6 +192,63 @@ def run_cli(cmd):
         if line.startswith("BBK_PHASES "):
             ph = json.loads(line[len("BBK_PHASES "):])
     return {"wall_s": wall, "phases": ph}
+
+
+def cpp_multi_gpu(ctx, args, world):
+    """N > 1 only, rank 0, after the timed region: the C++ one-process host (`spades-kmercount --devices 0,..,N-1`:
+    one host thread + context per GPU, owner-hash shards, ONE grouped ncclSend/ncclRecv all-to-all, bucket-wise merge
+    into one final_kmers) on the node's GPUs, beside the single-device tool on the same FASTA: wall times and whether
+    the two files are the same bytes.  The only place where the RCCL path of the C++ host meets more than one GPU (the
+    build box has one); any failure is reported in the object, never raised."""
+    import hashlib
+    import tempfile
+    from spades_for_blackbird_amd import build_host
+    out = {"devices": world}
+    d = tempfile.mkdtemp(prefix="bbk_cpp_multi_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        n = min(args.reads, 2_000_000) * world
+        r = ctx.reads_synth(n, read_len=args.read_len, genome_len=max(args.read_len, n * args.read_len // 50), seed_reads=77)
+        fa = os.path.join(d, "reads.fa")
+        write_fasta(r, fa)
+        r.free()
+        ctx.trim()
+        out["reads"] = n
+        bins = {os.path.basename(p): p for p in build_host.build()}
+
+        def md5(path):
+            h = hashlib.md5()
+            with open(path, "rb") as f:
+                for b in iter(lambda: f.read(1 << 26), b""):
+                    h.update(b)
+            return h.hexdigest()
+        devs = ",".join(str(i) for i in range(world))
+        # BBK_BENCH_CPP_MULTI_ARGS="--devices 0,0 --exchange copy": rehearsal on a box with fewer GPUs than ranks
+        multi = os.environ.get("BBK_BENCH_CPP_MULTI_ARGS", "--devices " + devs).split()
+        out["args"] = " ".join(multi)
+        res = {}
+        for name, extra in (("single_device", ["--device", "0"]), ("all_devices_rccl", multi)):
+            w = os.path.join(d, name)
+            os.makedirs(w, exist_ok=True)
+            res[name] = run_cli([bins["spades-kmercount"], "-k", str(args.k), "-t", "16", "-w", w, fa] + extra, timeout=300)
+            fk = os.path.join(w, "final_kmers")
+            if os.path.exists(fk):
+                res[name]["final_kmers_bytes"] = os.path.getsize(fk)
+                res[name]["md5"] = md5(fk)
+                os.unlink(fk)
+        out["kmercount"] = res
+        out["final_kmers_identical"] = bool(res["single_device"].get("md5")) and \
+            res["single_device"].get("md5") == res["all_devices_rccl"].get("md5")
+        gfa = os.path.join(d, "g.gfa")
+        out["gbuilder_all_devices_rccl"] = run_cli([bins["spades-gbuilder"], fa, gfa, "-k", str(args.k), "-t", "16", "--gfa",
+                                                    ] + multi, timeout=300)
+        if os.path.exists(gfa):
+            out["gbuilder_all_devices_rccl"]["gfa_bytes"] = os.path.getsize(gfa)
+    except Exception as ex:
+        out["error"] = repr(ex)[:300]
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 def e2e(ctx, reads, args):
@@ -452,6 +512,24 @@ def main():
             os.unlink(path)
             u.free()
 
+    # N > 1: the C++ one-process host over RCCL on the same GPUs, once, outside every timed region (rank 0 runs the
+    # tools; all ranks hand their device memory back first and wait)
+    cpp_multi = None
+    if world > 1 and not args.no_e2e and os.environ.get("BBK_BENCH_CPP_MULTI", "1") != "0":
+        try:
+            ctx.trim()
+            torch.cuda.empty_cache()
+            fence()
+            # the other ranks wait on the HOST (a gloo barrier): an RCCL barrier would park a spinning kernel on the very
+            # GPUs the tools are about to use
+            cpu_group = dist.new_group(backend="gloo")
+            dist.barrier(group=cpu_group)
+            if rank == 0:
+                cpp_multi = cpp_multi_gpu(ctx, args, world)
+            dist.barrier(group=cpu_group)
+        except Exception as ex:
+            cpp_multi = {"error": repr(ex)[:300]}
+
     if rank == 0:
         def pmc(dom):
             same = (args.reads, L, k, world, args.ext_index) == (PMC_WORKLOAD["reads"], PMC_WORKLOAD["read_len"],
@@ -512,6 +590,8 @@ def main():
             line["gfa_build"] = gfa_build(ctx, reads, k)
         if gfa_sharded:
             line["gfa_build"] = gfa_sharded
+        if cpp_multi:
+            line["cpp_one_process_multi_gpu"] = cpp_multi
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ctx, args, B)
         print(json.dumps(line), flush=True)

@@ -117,3 +117,18 @@ def test_no_kernel_uses_scratch():
         pytest.skip("llvm-objdump / llvm-readelf not installed")
     assert len(res) > 150  # all instantiations of all eight translation units are seen
     assert all(r[2] == 0 and r[4] == 0 for r in res)
+
+
+def test_final_kmers_merge_of_shards_fuzz(tmp_path):
+    """host/multi.hpp: write_final_kmers_merged (the writer of `spades-kmercount --devices`) against a plain sort, for
+    1..8 shards, 1..4-word records, empty shards / buckets; host-only, AddressSanitizer + UBSan."""
+    from spades_for_blackbird_amd import build as b
+    b.build()
+    exe = str(tmp_path / "merge_fuzz")
+    lib = os.path.join(ROOT, "spades_for_blackbird_amd")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fopenmp", "-fsanitize=address,undefined", "-o", exe,
+                           os.path.join(ROOT, "tests", "merge_fuzz.cpp"), "-L" + lib, "-lbbk", "-lz", "-Wl,-rpath," + lib])
+    for seed in (1, 2, 3):
+        r = subprocess.run([exe, str(seed), str(tmp_path / "merged.bin")], capture_output=True, text=True,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        assert r.returncode == 0 and "MERGE-FUZZ-OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
