@@ -709,12 +709,15 @@ __global__ __launch_bounds__(kRadix) void k_tile_offsets(uint32_t *__restrict__ 
                                                         const uint64_t *__restrict__ chunk_base) {
     const uint64_t t0 = (uint64_t)blockIdx.x * kChunk;
     const uint64_t t1 = (t0 + kChunk < ntiles) ? t0 + kChunk : ntiles;
-    uint64_t run = chunk_base[(uint64_t)blockIdx.x * kRadix + threadIdx.x];
+    // offsets RELATIVE to the chunk's base (a chunk of 256 tiles holds < 2^32 records): the scatter kernel adds the
+    // 64-bit base, so that an array of 2^32 records or more sorts like any other
+    uint32_t run = 0;
     for (uint64_t t = t0; t < t1; ++t) {
         uint32_t v = hist[t * kRadix + threadIdx.x];
-        hist[t * kRadix + threadIdx.x] = (uint32_t)run;
+        hist[t * kRadix + threadIdx.x] = run;
         run += v;
     }
+    (void)chunk_base;
 }
 
 // wavefront match-any on an 8-bit digit: mask of lanes (among `valid` lanes) holding the same digit
@@ -733,11 +736,12 @@ template <int W, bool HAS_VAL>
 __global__ __launch_bounds__(kThreads) void k_scatter(const Key<W> *__restrict__ in, Key<W> *__restrict__ out,
                                                      const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout,
                                                      uint64_t n, PassDesc pd,
-                                                     const uint32_t *__restrict__ tile_off) {
+                                                     const uint32_t *__restrict__ tile_off,
+                                                     const uint64_t *__restrict__ chunk_base) {
     constexpr int ITEMS = SortCfg<W>::ITEMS, TILE = SortCfg<W>::TILE;
     __shared__ uint32_t wave_cnt[kWaves][kRadix];
     __shared__ uint32_t digit_start[kRadix];
-    __shared__ uint32_t goff[kRadix];
+    __shared__ uint64_t goff[kRadix];
     __shared__ uint32_t scan_tmp[kWaves + 1];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
     Key<W> *stage = reinterpret_cast<Key<W> *>(dyn_smem);
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter(const Key<W> *__restrict__
     uint32_t tile_total;
     const uint32_t dstart = block_excl_scan(tot, scan_tmp, &tile_total);
     digit_start[tid] = dstart;
-    goff[tid] = tile_off[tile * kRadix + tid] - dstart;  // wraps mod 2^32; added back below
+    goff[tid] = chunk_base[(tile / kChunk) * kRadix + tid] + tile_off[tile * kRadix + tid] - dstart;  // + pos below
     __syncthreads();
 
 #pragma unroll
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(kThreads) void k_scatter(const Key<W> *__restrict__
         if (pos < tile_n) {
             const Key<W> key = key_load<W>(&stage[pos]);
             const uint32_t d = digit_of<W>(key, &stage[pos], pd);
-            const uint32_t g = goff[d] + pos;
+            const uint64_t g = goff[d] + pos;
             key_store<W>(&out[g], key);
             if (HAS_VAL) vout[g] = vstage[pos];
         }
@@ -861,10 +865,10 @@ static void sort_pass(bbk_ctx *ctx, const Key<W> *src, Key<W> *dst, const uint32
         KernelTimer t(ctx, "scatter", 2.0 * (double)n * rec_bytes);
         if (hv) {
             hipLaunchKernelGGL((k_scatter<W, true>), dim3((unsigned)ntiles), dim3(kThreads), dyn, ctx->stream, src, dst,
-                               vsrc, vdst, n, pd, hist.as<uint32_t>());
+                               vsrc, vdst, n, pd, hist.as<uint32_t>(), chunk.as<uint64_t>());
         } else {
             hipLaunchKernelGGL((k_scatter<W, false>), dim3((unsigned)ntiles), dim3(kThreads), dyn, ctx->stream, src, dst,
-                               (const uint32_t *)nullptr, (uint32_t *)nullptr, n, pd, hist.as<uint32_t>());
+                               (const uint32_t *)nullptr, (uint32_t *)nullptr, n, pd, hist.as<uint32_t>(), chunk.as<uint64_t>());
         }
         check_launch("k_scatter");
     }
@@ -872,8 +876,7 @@ static void sort_pass(bbk_ctx *ctx, const Key<W> *src, Key<W> *dst, const uint32
 
 template <int W>
 static void sort_scratch(uint64_t n, bool with_vals, DevBuf &hist, DevBuf &chunk) {
-    BBK_REQUIRE(n < (1ull << 32), BBK_ERR_ARG, "sort_records: n=%llu does not fit 32-bit offsets (batch the input)",
-                (unsigned long long)n);
+    BBK_REQUIRE(n < (1ull << 40), BBK_ERR_ARG, "sort_records: n=%llu", (unsigned long long)n);
     constexpr int TILE = SortCfg<W>::TILE;
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     const uint64_t nchunks = (ntiles + kChunk - 1) / kChunk;

@@ -534,8 +534,8 @@ static void build(bbk_ctx *ctx, bbk_extindex *x, bbk_unitigs &U, unsigned ref_th
     BBK_REQUIRE(NU <= E && NB <= 2 * n + (uint64_t)(k + 1) * NU, BBK_ERR_INTERNAL,
                 "unitig walk: %llu unitigs / %llu bases from %llu start edges, %llu k-mers", (unsigned long long)NU,
                 (unsigned long long)NB, (unsigned long long)E, (unsigned long long)n);
-    // edge ids travel as the u32 payload of the link-record sort, whose offsets are 32-bit: 2 NU < 2^32
-    BBK_REQUIRE(NU < (1ull << 31), BBK_ERR_ARG, "%llu unitigs: the link-record sort takes 2^31 - 1 edges", (unsigned long long)NU);
+    // edge ids travel as the u32 payload of the link-record sort
+    BBK_REQUIRE(NU < (1ull << 32) - 1, BBK_ERR_ARG, "%llu unitigs: edge ids are 32-bit", (unsigned long long)NU);
 
     // ---- pass 1: bases + link records
     DevBuf bases(NB + 16), uoff((NU + 1) * 8), rec((2 * NU + 2) * 8), selfc(NU + 16);
@@ -990,7 +990,7 @@ int bbk_unitigs_export_links(bbk_ctx *ctx, const bbk_unitigs *u, uint32_t *h_lin
         BBK_REQUIRE(ctx && u && (u->n_links == 0 || h_links), BBK_ERR_ARG, "bbk_unitigs_export_links: NULL argument");
         ensure_host(ctx, u);
         for (uint64_t l = 0; l < u->n_links; ++l) {
-            h_links[4 * l] = (uint32_t)(u->links[2 * l] >> 1);  // edge ids are below 2^31 (build)
+            h_links[4 * l] = (uint32_t)(u->links[2 * l] >> 1);  // edge ids are below 2^32 - 1 (build)
             h_links[4 * l + 1] = (uint32_t)(u->links[2 * l] & 1u);
             h_links[4 * l + 2] = (uint32_t)(u->links[2 * l + 1] >> 1);
             h_links[4 * l + 3] = (uint32_t)(u->links[2 * l + 1] & 1u);

@@ -110,6 +110,35 @@ def _graph64():
     ck = torch.empty((n_e, 1), dtype=torch.int64, device="cuda")
     cc = torch.empty(n_e, dtype=torch.int32, device="cuda")
     cu.export_to(ck, B.ORDER_SORTED, dst_counts=cc)
+    # the same set in the final_kmers order (16 hash buckets, ascending inside each: one stable LSD pass whose
+    # offsets must be 64-bit here) and partitioned by owner -- the two exports the writers and the exchange use
+    def sums(t):
+        a = b = 0
+        for a0 in range(0, n_e, 1 << 28):
+            v = t[a0:a0 + (1 << 28)].reshape(-1)
+            a = (a + int(v.sum().item())) & ((1 << 64) - 1)
+            b = (b + int((v * v).sum().item())) & ((1 << 64) - 1)
+        return a, b
+
+    def descents(t):
+        d = 0
+        for a0 in range(0, n_e - 1, 1 << 28):
+            v = t[a0:a0 + (1 << 28) + 1, 0]
+            d += int((v[1:] < v[:-1]).sum().item())
+        return d
+    want = sums(ck)
+    assert descents(ck) == 0
+    n_two = int(sum(int((cc[a0:a0 + (1 << 28)] == 2).sum().item()) for a0 in range(0, n_e, 1 << 28)))
+    ck2 = torch.empty_like(ck)
+    cc2 = torch.empty_like(cc)
+    cu.export_to(ck2, B.ORDER_REFERENCE_BUCKETS16, dst_counts=cc2)
+    assert sums(ck2) == want and descents(ck2) == 15, descents(ck2)
+    assert int(sum(int((cc2[a0:a0 + (1 << 28)] == 2).sum().item()) for a0 in range(0, n_e, 1 << 28))) == n_two
+    per_owner = cu.export_by_owner(8, dst_keys=ck2, dst_counts=cc2)
+    assert int(sum(per_owner)) == n_e and min(per_owner) > n_e // 8 - (1 << 20), per_owner
+    assert sums(ck2) == want and descents(ck2) == 7, descents(ck2)
+    del ck2, cc2
+    lap("bucket + owner partitions of %d records: same multiset, 16 / 8 ascending runs" % n_e)
     cu.free()
     del ck
     assert int(cc.max().item()) <= 2 and int(cc.min().item()) == 1
