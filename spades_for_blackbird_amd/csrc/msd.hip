@@ -114,23 +114,22 @@ struct PartLevel {
     int narrow_hb;
     // narrow level 1: every segment slot is cut into 2^xcd_shift sub-slots of sub_cap records, one per XCD, with a
     // cursor each (cursor[(bin << xcd_shift) + xcc]).  A (tile, bin) run is ~60 bytes and starts wherever the last one
-    // ended; with one fill front per bin the two halves of a 32-byte sector come from workgroups on different XCDs,
-    // whose L2s each write their part back (1.5x the algorithmic bytes reached HBM).  With a fill front per (bin, XCD)
-    // the partial sectors were expected to meet in ONE L2 and leave it complete (they do not: see the call site).  Level 2
+    // ended; with one fill front per bin a 128-byte line is filled by workgroups on different XCDs, i.e. through
+    // different L2s, which is slow (see the call site).  With a fill front per (bin, XCD) every line is one XCD's.  Level 2
     // reads the sub-slots as segments of their own and sends them to the buckets of the parent segment.
     int xcd_shift;
     uint32_t sub_cap;
 };
 
 // ---- narrow records (stage A, 17 <= k <= 21) ---------------------------------------------------------------
-// A k-mer of 2k <= 42 bits is (hi: 2k - 32 bits, lo: 32 bits = its first 16 bases).  Level 1 sends it to segment
-//   bin1 = hi ^ G(lo)            (G: hb bits of a multiplicative mix of lo; for hb < 10 the bin is filled up to 10 bits
-//                                 with further hash bits of lo)
-// and stores ONLY lo: inside a segment lo determines hi (= bin1 ^ G(lo)), so 4-byte records are exact -- equal lo <=>
-// equal k-mer.  Level 2 and the in-LDS dedup work on lo alone (their bins / slots are other bits of the same mix),
-// the dedup kernel rebuilds the 8-byte key from (segment, lo) when it writes the distinct records.  The canonical
-// stream -- 1.3 G records at BASELINE configs[1], 8.3x the distinct set -- travels as 4 bytes per record instead of 8
-// through its three passes (level-1 write, level-2 read + write, dedup read).
+// A k-mer of 2k <= 42 bits is (hi: 2k - 32 = hb bits, lo: 32 bits = its first 16 bases).  With t = mix(lo), level 1
+// sends it to segment
+//   bin1 = (t >> 22) ^ (hi << (10 - hb))      (the top ten hash bits of lo, hi folded into the upper hb of them)
+// and stores ONLY lo: inside a segment lo determines hi (= (bin1 ^ t >> 22) >> (10 - hb)), so 4-byte records are exact --
+// equal lo <=> equal k-mer.  Level 2 and the in-LDS dedup work on lo alone (their bins / slots are other bits of the
+// same mix), the dedup kernel rebuilds the 8-byte key from (segment, lo) when it writes the distinct records.  The
+// canonical stream -- 1.3 G records at BASELINE configs[1], 8.3x the distinct set -- travels as 4 bytes per record
+// instead of 8 through its three passes (level-1 write, level-2 read + write, dedup read).
 constexpr int kNwBins1 = 1024;
 __device__ inline uint32_t nw_mix(uint32_t lo) {
     uint32_t t = lo * 0x9E3779B1u;
@@ -139,16 +138,12 @@ __device__ inline uint32_t nw_mix(uint32_t lo) {
     t ^= t >> 13;
     return t;
 }
-__device__ inline uint32_t nw_g(uint32_t t, int hb) { return ((t * 0xC2B2AE35u) >> 22) & ((1u << hb) - 1u); }
 __device__ inline uint32_t nw_slot(uint32_t t) { return (t * 0x27D4EB2Fu) >> 19; }  // 13 bits for the LDS table
-__device__ inline uint32_t nw_bin1(uint32_t hi, uint32_t t, int hb) {
-    const uint32_t hp = hi ^ nw_g(t, hb);
-    return hb >= 10 ? hp : (hp << (10 - hb)) | (t >> (22 + hb));
-}
+__device__ inline uint32_t nw_bin1(uint32_t hi, uint32_t t, int hb) { return (t >> 22) ^ (hi << (10 - hb)); }
 // prefix for level 2: the bits of the mix that level 1 has not used (top-aligned)
-__device__ inline uint32_t nw_p2(uint32_t t, int hb) { return hb >= 10 ? t : t << (10 - hb); }
+__device__ inline uint32_t nw_p2(uint32_t t) { return t << 10; }
 __device__ inline uint64_t nw_key(uint32_t bin1, uint32_t lo, int hb) {
-    const uint32_t hi = (bin1 >> (10 - hb)) ^ nw_g(nw_mix(lo), hb);
+    const uint32_t hi = (bin1 ^ (nw_mix(lo) >> 22)) >> (10 - hb);
     return ((uint64_t)hi << 32) | lo;
 }
 
@@ -218,7 +213,7 @@ __device__ inline uint64_t read_at(const uint64_t *__restrict__ off, uint64_t n_
 __global__ void k_tile_reads(const uint64_t *__restrict__ coff, const uint64_t *__restrict__ woff,
                              const uint32_t *__restrict__ len, uint64_t n_reads, uint64_t n_tiles, uint32_t tile,
                              uint32_t ch, uint32_t k, uint32_t max_reads, uint32_t max_words,
-                             RdTile *__restrict__ out) {
+                             const uint32_t *__restrict__ unordered, RdTile *__restrict__ out) {
     const uint64_t t = BBK_GID();
     if (t >= n_tiles) return;
     const uint64_t c0 = t * (uint64_t)tile;
@@ -232,7 +227,8 @@ __global__ void k_tile_reads(const uint64_t *__restrict__ coff, const uint64_t *
     const uint32_t lastb1 = len1 ? (uint32_t)(span1 < (uint64_t)(len1 - 1u) ? span1 : (uint64_t)(len1 - 1u)) : 0u;
     const uint64_t wend = woff[r1] + (len1 ? (lastb1 >> 5) + 1u : 0u);
     const uint64_t nr = r1 - r0 + 1;
-    const bool fast = nr <= (uint64_t)max_reads && wend >= wbase && wend - wbase <= (uint64_t)max_words;
+    // words in read order (checked once for all reads): every read of the tile then lies inside [wbase, wend)
+    const bool fast = *unordered == 0 && nr <= (uint64_t)max_reads && wend >= wbase && wend - wbase <= (uint64_t)max_words;
     RdTile T;
     T.wbase = wbase;
     T.r0 = (uint32_t)r0;
@@ -323,6 +319,34 @@ __device__ unsigned long long g_phase[6][8];
 // bin << 16 | rank-in-bin (0xFFFFFFFF: no record).  One global atomicAdd per non-empty bin reserves the
 // tile's run in that bin; the records are reordered through LDS (stage) so that a wave stores contiguous
 // per-bin runs.
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts: six v_add with a DPP operand.
+// (__shfl_up goes through ds_bpermute: an address register per distance, an LDS-pipe operation and a select per step.)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
+    return v;
+}
+
+// Per-wave totals (nw <= 64 values in LDS, written before the last barrier) -> the sum of the waves before `wave` and
+// the grand total.  Every wave scans the few values itself: log2(nw) shuffle steps instead of a loop of nw LDS reads
+// per thread (which was ~80 vector instructions per thread in a workgroup of 16 waves).
+template <int NW>
+__device__ __forceinline__ void wave_totals(const uint32_t *tmp, int lane, int wave, uint32_t &before, uint32_t &total) {
+    static_assert(NW <= 16, "one DPP row");
+    const uint32_t v = lane < NW ? tmp[lane] : 0u;
+    uint32_t inc = v;
+    if (NW > 1) inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);
+    if (NW > 2) inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);
+    if (NW > 4) inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);
+    if (NW > 8) inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)inc, NW - 1);
+    before = (uint32_t)__builtin_amdgcn_readlane((int)(inc - v), __builtin_amdgcn_readfirstlane(wave));
+}
+
 template <int W, int ITEMS, int THREADS, int MAXB, bool HAS_VAL>
 __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uint32_t (&vals)[ITEMS],
                                           const uint32_t (&binrank)[ITEMS], uint32_t *lhist, uint32_t *lstart,
@@ -349,18 +373,11 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
         }
         const int lane = tid & 63, wave = tid >> 6;
         uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
+        incl = wave_scan_incl(incl);
         if (lane == 63) scan_tmp[wave] = incl;
         __syncthreads();
-        uint32_t wbase = 0, all = 0;
-        for (int w = 0; w < THREADS / 64; ++w) {
-            if (w < wave) wbase += scan_tmp[w];
-            all += scan_tmp[w];
-        }
+        uint32_t wbase, all;
+        wave_totals<THREADS / 64>(scan_tmp, lane, wave, wbase, all);
         staged = all;  // records of this tile that take part
         ex0 = wbase + incl - v;
         uint32_t ex = ex0;
@@ -384,6 +401,10 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
             if (HAS_VAL) vstage[pos] = vals[i];
         }
     }
+    // the reservations' results are awaited HERE, by every lane: the compiler otherwise puts the wait for them (vmcnt 0)
+    // into the conditional blocks of the store loop below, where it makes every store wait for the one before
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) asm volatile("" : "+v"(greserve[q]));
     {
         uint32_t ex = ex0;
 #pragma unroll
@@ -403,6 +424,11 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
     __syncthreads();
     BBK_PH(prof_kind, 3, t_prev);  // reorder into LDS
 
+    // A bin whose slot is full (a k-mer repeated far beyond the coverage, a crowded bucket) spills.  Rare, and handled
+    // after the stores: the spill counter's atomic returns a value, and a wait for it between the stores would make
+    // every store wait for the one before.
+    uint32_t full = 0;
+    static_assert(ITEMS <= 32, "one bit per item");
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t pos = (uint32_t)(i * THREADS + tid);
@@ -413,15 +439,23 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
             const uint32_t b = bin_of(pfx, L, nb);
             const uint32_t g = goff[b] + pos;
             if (L.slot_cap && (int32_t)pos >= (int32_t)lhist[b]) {
-                // the bin's slot is full (a k-mer repeated far beyond the coverage, a crowded bucket): spill
-                const uint32_t sp = atomicAdd(L.spill_count, 1u);
-                if (sp < L.spill_cap) {
-                    key_store<W>(&reinterpret_cast<Key<W> *>(L.spill_keys)[sp], key);
-                    if (HAS_VAL) L.spill_vals[sp] = vstage[pos];
-                }
+                full |= 1u << i;
             } else {
                 key_store<W>(&out[g], key);
                 if (HAS_VAL) vout[g] = vstage[pos];
+            }
+        }
+    }
+    if (full) {
+#pragma unroll 1
+        for (int i = 0; i < ITEMS; ++i) {
+            if ((full >> i) & 1u) {
+                const uint32_t pos = (uint32_t)(i * THREADS + tid);
+                const uint32_t sp = atomicAdd(L.spill_count, 1u);
+                if (sp < L.spill_cap) {
+                    key_store<W>(&reinterpret_cast<Key<W> *>(L.spill_keys)[sp], key_load<W>(&stage[pos]));
+                    if (HAS_VAL) L.spill_vals[sp] = vstage[pos];
+                }
             }
         }
     }
@@ -728,17 +762,11 @@ __device__ __forceinline__ void chunk_records(const ChunkWords C, uint32_t k_, c
                 if (p >= 1) m |= 1u << (minimal ? 4u + prevc : 3u - prevc);
                 vals[i] = m;
             }
-            if (W == 1 && L.narrow_hb) {  // narrow stage A: bin from (hi, mix(lo)); rank < 16384
-                const uint32_t b = nw_bin1((uint32_t)(keys[i].w[0] >> 32), nw_mix((uint32_t)keys[i].w[0]), L.narrow_hb);
+            uint32_t pfx = part_hash32<W>(keys[i]);
+            if (select_prefix(pfx, L)) {
+                const uint32_t b = L.b1 == 0 ? 0u : (pfx >> (32 - L.b1));
                 const uint32_t rank = atomicAdd(&lhist[b], 1u);
                 binrank[i] = (b << 16) | rank;
-            } else {
-                uint32_t pfx = part_hash32<W>(keys[i]);
-                if (select_prefix(pfx, L)) {
-                    const uint32_t b = L.b1 == 0 ? 0u : (pfx >> (32 - L.b1));
-                    const uint32_t rank = atomicAdd(&lhist[b], 1u);
-                    binrank[i] = (b << 16) | rank;
-                }
             }
         }
     }
@@ -935,7 +963,7 @@ __device__ __forceinline__ void bucket_reduce(Key<W> *skeys, uint32_t *svals, ui
     constexpr int NWAVES = NT / 64;
     constexpr bool IN_VAL = OP >= 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t ostart = (A.sorted_keys && A.out_off) ? A.out_off[b] : start;  // where the sorted records go
+    uint32_t ostart = (A.sorted_keys && A.out_off) ? A.out_off[b] : start;  // where the sorted records go
     Key<W> mine[ITEMS];
     uint32_t mv[ITEMS];
     const uint32_t p0 = (uint32_t)tid * ITEMS;
@@ -963,21 +991,17 @@ __device__ __forceinline__ void bucket_reduce(Key<W> *skeys, uint32_t *svals, ui
     uint32_t excl, total;
     {
         uint32_t incl = nheads;
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            uint32_t t = __shfl_up(incl, dd, 64);
-            if (lane >= dd) incl += t;
-        }
+        incl = wave_scan_incl(incl);
         __syncthreads();  // everyone has its keys in registers: skeys may be reused below
         if (lane == 63) scan_tmp[wave] = incl;
         __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-        for (int j = 0; j < NWAVES; ++j) {
-            if (j < wave) wbase += scan_tmp[j];
-            tot += scan_tmp[j];
-        }
+        uint32_t wbase, tot;
+        wave_totals<NWAVES>(scan_tmp, lane, wave, wbase, tot);
         excl = wbase + incl - nheads;
         total = tot;
+        // the loaded offset is awaited HERE by every lane: left to the compiler, the wait (vmcnt 0) lands in the
+        // conditional blocks of the store loop below and makes every store wait for the one before
+        asm volatile("" : "+v"(ostart));
     }
     uint32_t *acc = reinterpret_cast<uint32_t *>(skeys);  // CAP u32 fit in the key buffer
     if (OP != 0) {
@@ -1159,11 +1183,7 @@ __global__ __launch_bounds__(NT) void k_bucket(Key<W> *__restrict__ buf, uint32_
                         tot += c;
                     }
                     incl = tot;
-#pragma unroll
-                    for (int dd = 1; dd < 64; dd <<= 1) {
-                        uint32_t t = __shfl_up(incl, dd, 64);
-                        if (lane >= dd) incl += t;
-                    }
+                    incl = wave_scan_incl(incl);
                     if (lane == 63) scan_tmp[wave] = incl;
                 }
                 __syncthreads();
@@ -1334,11 +1354,7 @@ __global__ __launch_bounds__(NT) void k_bucket_dist(Key<W> *__restrict__ buf, ui
         big = big || c[q] > kDistMaxBin;
     }
     uint32_t incl = sum;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        uint32_t t = __shfl_up(incl, dd, 64);
-        if (lane >= dd) incl += t;
-    }
+    incl = wave_scan_incl(incl);
     if (lane == 63) scan_tmp[wave] = incl;
     if (__syncthreads_or(big)) {  // nothing has been written: the second-chance kernel takes the bucket
         if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
@@ -1589,18 +1605,11 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
 #pragma unroll
     for (int j = 0; j < SPT; ++j) cnt += tab[j * kHashThreads + tid] != EMPTY ? 1u : 0u;
     uint32_t incl = cnt;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        uint32_t t = __shfl_up(incl, dd, 64);
-        if (lane >= dd) incl += t;
-    }
+    incl = wave_scan_incl(incl);
     if (lane == 63) scan_tmp[wave] = incl;
     __syncthreads();
-    uint32_t wbase = 0, total = 0;
-    for (int j = 0; j < kHashThreads / 64; ++j) {
-        if (j < wave) wbase += scan_tmp[j];
-        total += scan_tmp[j];
-    }
+    uint32_t wbase, total;
+    wave_totals<kHashThreads / 64>(scan_tmp, lane, wave, wbase, total);
     Key<1> *obuf = buf;
     uint32_t *ovals = vals;
     uint32_t obase = start;
@@ -1712,18 +1721,11 @@ __global__ __launch_bounds__(kHashIdxThreads) void k_bucket_hashidx(Key<W> *__re
 #pragma unroll
     for (int j = 0; j < SPT; ++j) cnt += tab[j * kHashIdxThreads + tid] != EMPTY ? 1u : 0u;  // no bank conflicts
     uint32_t incl = cnt;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        uint32_t t = __shfl_up(incl, dd, 64);
-        if (lane >= dd) incl += t;
-    }
+    incl = wave_scan_incl(incl);
     if (lane == 63) scan_tmp[wave] = incl;
     __syncthreads();
-    uint32_t wbase = 0, total = 0;
-    for (int j = 0; j < kHashIdxThreads / 64; ++j) {
-        if (j < wave) wbase += scan_tmp[j];
-        total += scan_tmp[j];
-    }
+    uint32_t wbase, total;
+    wave_totals<kHashIdxThreads / 64>(scan_tmp, lane, wave, wbase, total);
     Key<W> *obuf = buf;
     uint32_t *ovals = vals;
     uint32_t obase = start;
@@ -1816,15 +1818,18 @@ __global__ void k_scan_to_u32(const uint64_t *__restrict__ in, uint64_t n, uint6
     if (i == n) out[n] = (uint32_t)total;
 }
 
-// k-mers and chunks (of ch k-mer positions) of every read
-__global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, uint64_t n, uint32_t k, uint32_t ch,
-                                  uint64_t *__restrict__ nk, uint64_t *__restrict__ nch) {
+// k-mers and chunks (of ch k-mer positions) of every read; *unordered is set when the packed words of the reads do not
+// lie one after the other in read order (then no tile stages its window of words in LDS: k_tile_reads)
+__global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, const uint64_t *__restrict__ woff, uint64_t n,
+                                  uint32_t k, uint32_t ch, uint64_t *__restrict__ nk, uint64_t *__restrict__ nch,
+                                  uint32_t *__restrict__ unordered) {
     const uint64_t i = BBK_GID();
     if (i < n) {
         const uint32_t L = len[i];
         const uint64_t c = L >= k ? (uint64_t)(L - k + 1) : 0ull;
         nk[i] = c;
         nch[i] = (c + ch - 1) / ch;
+        if (i + 1 < n && woff[i + 1] < woff[i] + ((L + 31u) >> 5)) *unordered = 1u;
     }
 }
 
@@ -1832,7 +1837,7 @@ __global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, uint64_t n, 
 // narrow stage A kernels (4-byte records, see "narrow records" above): level 1 from reads, level 2, dedup
 // ------------------------------------------------------------------------------------------
 constexpr int kNwThreads = 1024;
-constexpr int kNwRounds = 2;      // chunks of 8 k-mer positions per lane (the second round is 7/8 populated)
+constexpr int kNwRounds = 2;      // consecutive chunks of 8 k-mer positions per lane (the last 64 lanes of a full tile idle)
 constexpr int kNwChunks = 1920;   // chunks of a level-1 tile: 15360 records = 60 KB staged, runs of ~15 per bin;
                                   // (x 8 records) with the tables 77 KB of LDS: two workgroups per CU
 // with a payload (one mask byte per record: the extension index) the same tile would take 94 KB = ONE workgroup per CU
@@ -1844,72 +1849,156 @@ struct NwCfg {
     static constexpr int TILE = CHUNKS * 8;
 };
 
+// Eight consecutive k-mer positions of one read from ONE 64-bit window (narrow k: 8 + k + 1 <= 30 bases fit).  With
+// F = bases p .. p+31 (base p in the low bits) and NR = ~rev2(F) (the complement of base p at the top),
+//   a_i = F  << (64 - 2k - 2i)   is k-mer i top-aligned (its last base in the top bits, other bases of the read below),
+//   b_i = NR << 2i               is its reverse complement laid out the same way,
+// and the canonical k-mer (base-lexicographic minimum of the two, rtseq.hpp:407-415) is min(a_i, b_i) >> (64 - 2k):
+// comparing a k-mer x with rc(x) from the last base down decides like comparing them from the first base up (the first
+// difference from the start, x[j] against ~x[k-1-j], is also the first one from the end, ~x[j] against x[k-1-j]).
+// Two shifts, one compare, two selects per k-mer -- no carried state, against ~20 operations of the rolled form.
+template <bool HAS_VAL>
+__device__ __forceinline__ void nw_chunk(const uint64_t *rw, uint32_t p, uint32_t cnt, uint32_t len, uint32_t k_, int hb,
+                                         uint32_t *lhist, uint32_t (&lo)[8], uint32_t (&bins)[3], uint32_t (&masks)[2]) {
+    constexpr int CH = 8;
+    const uint32_t pad = 64u - 2u * k_;  // 22 .. 30
+    uint64_t F = 0, NR = 0;
+    uint32_t pb = 0;
+    if (cnt) {
+        F = bases_from(rw, p, (len - 1u) >> 5);
+        NR = ~rev2(F);
+        if (HAS_VAL) pb = p ? base_at(rw, p - 1u) : 0u;
+    }
+    bins[0] = bins[1] = bins[2] = 0;
+    masks[0] = masks[1] = 0;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        // (computed for idle positions too -- values, not branches: only the LDS atomic is conditional)
+        const uint64_t a = F << (pad - 2u * (uint32_t)i);
+        uint64_t b = NR << (2 * i);
+        // a palindrome counts as minimal (only the mask bits can tell): the unused low bits of b are set
+        if (HAS_VAL) b |= (1ull << pad) - 1ull;
+        const bool minimal = a <= b;
+        const uint64_t key = (minimal ? a : b) >> pad;
+        const uint32_t klo = (uint32_t)key;
+        const uint32_t bin = nw_bin1((uint32_t)(key >> 32), nw_mix(klo), hb);  // key < 4^k: bin < 1024
+        if (HAS_VAL) {
+            const uint32_t q = p + (uint32_t)i;
+            const uint32_t nextc = (uint32_t)(F >> (2u * ((uint32_t)i + k_))) & 3u;  // base q + k (i + k <= 28)
+            const uint32_t prevc = i == 0 ? pb : (uint32_t)(F >> (2 * (i > 0 ? i - 1 : 0))) & 3u;  // base q - 1
+            uint32_t m = 0;
+            if (q + k_ < len) m |= 1u << (minimal ? nextc : 7u - nextc);
+            if (q >= 1) m |= 1u << (minimal ? 4u + prevc : 3u - prevc);
+            masks[i >> 2] |= m << (8 * (i & 3));
+        }
+        if ((uint32_t)i < cnt) atomicAdd(&lhist[bin], 1u);  // count only: the place inside the bin is taken after the scan
+        lo[i] = klo;
+        bins[i / 3] |= bin << (10 * (i % 3));  // three 10-bit bins per register
+        // with the mask arithmetic eight interleaved positions need more registers than two workgroups per CU leave
+        if (HAS_VAL) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// read (relative to the tile's first read) that owns chunk c of the tile: rel[r] <= c < rel[r + 1].  Reads are about
+// equally long: the interpolated guess is right or off by one nearly always; otherwise a binary search.
+__device__ __forceinline__ uint32_t nw_read_of(const int32_t *s_rel, uint32_t nr, int32_t c, int32_t rel0, float scale) {
+    uint32_t g = (uint32_t)((float)(c - rel0) * scale);
+    g = g < nr ? g : nr - 1u;
+    if (s_rel[g] > c) --g;               // s_rel[0] <= 0 <= c: g stays >= 0
+    else if (s_rel[g + 1] <= c) ++g;     // s_rel[nr] > c for every chunk of the tile: g stays < nr
+    if (s_rel[g] > c || s_rel[g + 1] <= c) g = read_of(s_rel, nr, c);
+    return g;
+}
+
+// A lane extracts ROUNDS consecutive chunks (usually of one read: the owner of the first is looked up, the next ones
+// follow from it).
 template <bool FAST, bool HAS_VAL>
 __device__ __forceinline__ void nw_extract(const ReadSrc &S, const PartLevel &L, uint32_t k_, uint32_t tid, uint32_t nch,
                                            uint64_t c0, uint32_t r0, uint32_t nr, const int32_t *s_rel,
                                            const int32_t *s_wrel, const uint32_t *s_len, const uint64_t *s_words,
                                            uint32_t *lhist, uint32_t (&lo)[8 * NwCfg<HAS_VAL>::ROUNDS],
-                                           uint32_t (&binrank)[8 * NwCfg<HAS_VAL>::ROUNDS]) {
-    constexpr int CH = 8;
-#pragma unroll
-    for (int r = 0; r < NwCfg<HAS_VAL>::ROUNDS; ++r) {
-        const uint32_t ci = (uint32_t)r * kNwThreads + tid;  // chunk of this lane inside the tile
-        Key<1> kk[CH];
-        uint32_t vv[CH], br[CH];
+                                           uint32_t (&bins)[3 * NwCfg<HAS_VAL>::ROUNDS],
+                                           uint32_t (&masks)[2 * NwCfg<HAS_VAL>::ROUNDS], uint32_t &cnts) {
+    constexpr int CH = 8, R = NwCfg<HAS_VAL>::ROUNDS;
+    cnts = 0;  // records of round r in bits 4r .. 4r+3
+    const int hb = L.narrow_hb;
+    const uint32_t ci0 = tid * (uint32_t)R;
+    uint32_t ri = 0, p = 0, len = 0, nk = 0;
+    const uint64_t *rw = FAST ? s_words : S.words;
+    auto rel = [&](uint32_t i) -> int64_t {  // first chunk of read r0 + i, relative to the tile
+        return FAST ? (int64_t)s_rel[i] : (int64_t)(S.coff[(uint64_t)r0 + i] - c0);
+    };
+    auto enter = [&](uint32_t i) {  // per-read values
         if (FAST) {
-            ChunkWords C{s_words, 0, 0, 0};
-            if (ci < nch) {
-                const uint32_t ri = read_of(s_rel, nr, (int32_t)ci);
-                C.p = (uint32_t)((int32_t)ci - s_rel[ri]) * CH;
-                C.len = s_len[ri];
-                const uint32_t nk = C.len - k_ + 1u;
-                C.cnt = nk - C.p < (uint32_t)CH ? nk - C.p : (uint32_t)CH;
-                C.rw = s_words + s_wrel[ri];
-            }
-            chunk_records<1, CH, HAS_VAL>(C, k_, L, (uint32_t)kNwBins1, lhist, kk, vv, br);
+            len = s_len[i];
+            rw = s_words + s_wrel[i];
         } else {
-            ChunkWords C{S.words, 0, 0, 0};
-            if (ci < nch) {
-                const uint64_t c = c0 + ci;
-                uint64_t lo_r = r0, hi_r = (uint64_t)r0 + nr;  // largest r with coff[r] <= c
-                while (hi_r - lo_r > 1) {
-                    const uint64_t mid = (lo_r + hi_r) >> 1;
-                    if (S.coff[mid] <= c) lo_r = mid;
-                    else hi_r = mid;
-                }
-                C.p = (uint32_t)(c - S.coff[lo_r]) * CH;
-                C.len = S.len[lo_r];
-                const uint32_t nk = C.len - k_ + 1u;
-                C.cnt = nk - C.p < (uint32_t)CH ? nk - C.p : (uint32_t)CH;
-                C.rw = S.words + S.woff[lo_r];
+            len = S.len[(uint64_t)r0 + i];
+            rw = S.words + S.woff[(uint64_t)r0 + i];
+        }
+        nk = len - k_ + 1u;
+    };
+    if (ci0 < nch) {
+        if (FAST) {
+            const int32_t rel0 = s_rel[0];
+            const float scale = (float)nr / (float)(s_rel[nr] - rel0);
+            ri = nw_read_of(s_rel, nr, (int32_t)ci0, rel0, scale);
+        } else {
+            uint32_t a = 0, b = nr;  // largest i with rel(i) <= ci0
+            while (b - a > 1) {
+                const uint32_t mid = (a + b) >> 1;
+                if (rel(mid) <= (int64_t)ci0) a = mid;
+                else b = mid;
             }
-            chunk_records<1, CH, HAS_VAL>(C, k_, L, (uint32_t)kNwBins1, lhist, kk, vv, br);
+            ri = a;
         }
+        enter(ri);
+        p = (uint32_t)((int64_t)ci0 - rel(ri)) * CH;
+    }
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            lo[r * CH + i] = (uint32_t)kk[i].w[0];
-            // payload (8 mask bits) | bin (10 bits) | rank (< 16384): one register per record instead of two -- with a
-            // separate payload array the kernel needed 80 VGPRs, which is one workgroup of 1024 per CU instead of two
-            binrank[r * CH + i] = br[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu
-                                                       : ((HAS_VAL ? vv[i] << 24 : 0u) | ((br[i] >> 16) << 14) | (br[i] & 0x3FFFu));
+    for (int r = 0; r < R; ++r) {
+        const uint32_t ci = ci0 + (uint32_t)r;
+        uint32_t cnt = 0;
+        if (ci < nch) {
+            if (r > 0) {
+                p += CH;
+                if (p >= nk) {  // the next read that has chunks (rel(nr) lies beyond the tile: the walk ends)
+                    do ++ri;
+                    while (rel(ri + 1u) <= (int64_t)ci);
+                    enter(ri);
+                    p = 0;
+                }
+            }
+            cnt = nk - p < (uint32_t)CH ? nk - p : (uint32_t)CH;
         }
+        uint32_t l8[CH], b3[3], m2[2];
+        nw_chunk<HAS_VAL>(rw, p, cnt, len, k_, hb, lhist, l8, b3, m2);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) lo[r * CH + i] = l8[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bins[r * 3 + i] = b3[i];
+        masks[r * 2] = m2[0];
+        masks[r * 2 + 1] = m2[1];
+        cnts |= cnt << (4 * r);
     }
 }
 
-// Level 1: fused extraction (the chunk code of k_part_reads) + partition into 1024 segments.  The bin of a staged
-// record cannot be recomputed from lo alone, and a per-record side array would cost as much LDS as the stage itself:
-// the staged order is bin-major, so one bit per position marks where a non-empty bin starts and
-// bin(pos) = nz[#marks at or before pos - 1] (a 64-position word of marks is exactly what a wave handles per step).
+// Level 1: fused extraction + partition into 1024 segments.  The bin of a staged record cannot be recomputed from lo
+// alone, and a per-record side array would cost as much LDS as the stage itself: the staged order is bin-major, so
+// one bit per position marks where a non-empty bin starts and the r-th non-empty bin owns position pos when
+// r = #marks at or before pos - 1 (a 64-position word of marks is exactly what a wave handles per step).  What a
+// store needs of its bin -- global offset and room left in the slot -- sits in one 8-byte entry indexed by r.
 template <bool HAS_VAL>
-__global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, PartLevel L, uint32_t *__restrict__ cursor,
+__global__ __launch_bounds__(kNwThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_part_reads_narrow(ReadSrc S, PartLevel L, uint32_t ntiles,
+                                                                 uint32_t *__restrict__ cursor,
                                                                  uint32_t *__restrict__ out, uint32_t *__restrict__ vout) {
     constexpr int NT = kNwThreads, CH = 8, MAXB = kNwBins1, ITEMS = CH * NwCfg<HAS_VAL>::ROUNDS;
     constexpr int MW = NwCfg<HAS_VAL>::TILE / 64;  // 64-bit mark words
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *lstart = lhist + MAXB;
-    uint32_t *goff = lstart + MAXB;
-    uint32_t *scan_tmp = goff + MAXB;                                       // 64 entries
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem);                   // counts; later, with the next array:
+    uint2 *tab = reinterpret_cast<uint2 *>(smem);                           // r -> (global offset - staged start, limit)
+    uint32_t *lstart = lhist + 2 * MAXB;
+    uint32_t *scan_tmp = lstart + MAXB;                                     // 64 entries
     unsigned long long *mark = reinterpret_cast<unsigned long long *>(scan_tmp + 64);  // MW words
     uint16_t *mbase = reinterpret_cast<uint16_t *>(mark + MW);              // marks before every word
     uint16_t *nz = mbase + MW;                                              // r-th non-empty bin
@@ -1921,7 +2010,7 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
     uint32_t *stage = reinterpret_cast<uint32_t *>(U);
     uint8_t *vstage = reinterpret_cast<uint8_t *>(stage + NwCfg<HAS_VAL>::TILE);  // payloads of this path are 8 mask bits
 
-    const uint32_t tid = threadIdx.x;
+    uint32_t tid = threadIdx.x;
     const uint32_t k_ = (uint32_t)S.k;
     const int hb = L.narrow_hb;
     uint32_t xcc = 0;  // the XCD this workgroup runs on (placement is for speed only: any value gives a correct result)
@@ -1929,8 +2018,6 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= (1u << L.xcd_shift) - 1u;
     }
-    lhist[tid] = 0;  // NT == MAXB
-    if (tid < MW) mark[tid] = 0ull;
 #ifdef BBK_PHASE_PROF
     unsigned long long t_prev = clock64();
 #else
@@ -1938,141 +2025,179 @@ __global__ __launch_bounds__(kNwThreads) void k_part_reads_narrow(ReadSrc S, Par
     (void)t_prev;
 #endif
 
-    const uint32_t tile = blockIdx.x;
-    const uint64_t c0 = (uint64_t)tile * NwCfg<HAS_VAL>::CHUNKS;
-    const uint64_t left = S.n_chunks - c0;
-    const uint32_t nch = left < (uint64_t)NwCfg<HAS_VAL>::CHUNKS ? (uint32_t)left : (uint32_t)NwCfg<HAS_VAL>::CHUNKS;
-    const RdTile T = S.tiles[tile];
-    const uint32_t r0 = T.r0, nr = T.nr;
-    const uint64_t wbase = T.wbase;
-    bool fast = T.wspan != 0xFFFFFFFFu;
-    const uint32_t wspan = fast ? T.wspan : 0u;
-    const uint64_t wend = wbase + wspan;
-    if (fast) {
-        bool bad = false;
-        for (uint32_t i = tid; i <= nr; i += NT) {
-            const uint64_t rr = (uint64_t)r0 + i;
-            s_rel[i] = (int32_t)(int64_t)(S.coff[rr] - c0);
-            if (i < nr) {
-                const uint64_t wo = S.woff[rr];
-                const uint32_t ln = S.len[rr];
-                s_wrel[i] = (int32_t)(int64_t)(wo - wbase);
-                s_len[i] = ln;
-                if (i > 0 && wo < wbase) bad = true;
-                if (i + 1 < nr && wo + ((ln + 31u) >> 5) > wend) bad = true;
+    // A workgroup walks tiles blockIdx.x, + gridDim.x, ... (normally one: grid = tiles) and loads what the NEXT tile
+    // needs (its read tables and packed words: two dependent round trips to memory after the descriptor) into registers
+    // while it stores the current one.  One table entry and two words per thread: a tile with more reads or words than
+    // that takes the global-memory path (as does one not laid out in read order).
+    struct Pre {
+        uint64_t coff, woff, w0, w1;
+        uint32_t len;
+    };
+    auto staged_ok = [&](const RdTile &T) { return T.wspan != 0xFFFFFFFFu && T.nr < (uint32_t)NT && T.wspan <= 2u * NT; };
+    auto prefetch = [&](const RdTile &T, Pre &Q) {
+        Q = Pre{0, 0, 0, 0, 0};  // (the previous tile's values end here: they must not stay alive through the loop)
+        if (!staged_ok(T)) return;  // (uniform)
+        // unconditional loads, indices clamped into the tile's tables (a staged tile has >= 1 read and >= 1 word)
+        const uint32_t i0 = tid < T.nr ? tid : T.nr, i1 = tid < T.nr ? tid : T.nr - 1u;
+        const uint32_t j0 = tid < T.wspan ? tid : T.wspan - 1u, j1 = tid + NT < T.wspan ? tid + NT : T.wspan - 1u;
+        Q.coff = S.coff[(uint64_t)T.r0 + i0];
+        Q.woff = S.woff[(uint64_t)T.r0 + i1];
+        Q.len = S.len[(uint64_t)T.r0 + i1];
+        Q.w0 = S.words[T.wbase + j0];
+        Q.w1 = S.words[T.wbase + j1];
+    };
+
+    uint32_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    RdTile T = S.tiles[tile];
+    Pre Q{0, 0, 0, 0, 0};
+    prefetch(T, Q);
+    for (;;) {
+        // (the thread index is made opaque per iteration: the compiler otherwise computes every address that depends on
+        // it -- 16 stage positions, table slots ... -- once before the loop and keeps ~45 registers alive through it,
+        // which is one workgroup per CU instead of two)
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6;
+        const uint32_t tile_next = tile + gridDim.x;
+        const bool more = tile_next < ntiles;  // uniform: every wave of the workgroup leaves the loop together
+        RdTile Tn = T;
+        if (more) Tn = S.tiles[tile_next];
+
+        const uint64_t c0 = (uint64_t)tile * NwCfg<HAS_VAL>::CHUNKS;
+        const uint64_t left = S.n_chunks - c0;
+        const uint32_t nch = left < (uint64_t)NwCfg<HAS_VAL>::CHUNKS ? (uint32_t)left : (uint32_t)NwCfg<HAS_VAL>::CHUNKS;
+        const uint32_t r0 = T.r0, nr = T.nr;
+        const uint64_t wbase = T.wbase;
+        const bool fast = staged_ok(T);
+        lhist[tid] = 0;  // NT == MAXB
+        if (tid < 2 * MW) reinterpret_cast<uint32_t *>(mark)[tid] = 0u;
+        if (fast) {  // (a staged tile's reads lie inside its window of words: k_tile_reads)
+            if (tid <= nr) s_rel[tid] = (int32_t)(int64_t)(Q.coff - c0);
+            if (tid < nr) {
+                s_wrel[tid] = (int32_t)(int64_t)(Q.woff - wbase);
+                s_len[tid] = Q.len;
             }
+            if (tid < T.wspan) s_words[tid] = Q.w0;
+            if (tid + NT < T.wspan) s_words[tid + NT] = Q.w1;
         }
-        for (uint32_t i = tid; i < wspan; i += NT) s_words[i] = S.words[wbase + i];
-        fast = !__syncthreads_or(bad);
-    } else {
         __syncthreads();
-    }
+        BBK_PH(5, 0, t_prev);  // read tables + words into LDS
 
-    BBK_PH(5, 0, t_prev);  // read tables + words into LDS
-    uint32_t lo[ITEMS], binrank[ITEMS];
-    // (two instantiations: the address space of the packed words -- LDS or global -- must be static, a pointer that may
-    // be either compiles to flat loads)
-    if (fast) nw_extract<true, HAS_VAL>(S, L, k_, tid, nch, c0, r0, nr, s_rel, s_wrel, s_len, s_words, lhist, lo, binrank);
-    else nw_extract<false, HAS_VAL>(S, L, k_, tid, nch, c0, r0, nr, s_rel, s_wrel, s_len, s_words, lhist, lo, binrank);
-    __syncthreads();  // histogram complete; the read tables may be overwritten by the stage
-    BBK_PH(5, 1, t_prev);  // extraction + LDS ranking (two rounds)
+        uint32_t lo[ITEMS], bins[3 * NwCfg<HAS_VAL>::ROUNDS], masks[2 * NwCfg<HAS_VAL>::ROUNDS], cnts;
+        // (two instantiations: the address space of the packed words -- LDS or global -- must be static, a pointer that
+        // may be either compiles to flat loads)
+        if (fast) nw_extract<true, HAS_VAL>(S, L, k_, tid, nch, c0, r0, nr, s_rel, s_wrel, s_len, s_words, lhist, lo, bins, masks, cnts);
+        else nw_extract<false, HAS_VAL>(S, L, k_, tid, nch, c0, r0, nr, s_rel, s_wrel, s_len, s_words, lhist, lo, bins, masks, cnts);
+        __syncthreads();  // histogram complete; the read tables may be overwritten by the stage
+        BBK_PH(5, 1, t_prev);  // extraction + LDS ranking
 
-    // scan of the 1024 bin counts (one bin per thread) and of the non-empty flags; reservation of the tile's run
-    const int lane = tid & 63, wave = tid >> 6;
-    const uint32_t c = lhist[tid];
-    uint32_t incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += t;
-    }
-    const unsigned long long nzb = __ballot(c != 0);
-    if (lane == 63) scan_tmp[wave] = incl;
-    if (lane == 0) scan_tmp[32 + wave] = (uint32_t)__popcll(nzb);
-    __syncthreads();
-    uint32_t wb = 0, staged = 0, nzbase = 0;
-    for (int w = 0; w < NT / 64; ++w) {
-        if (w < wave) {
-            wb += scan_tmp[w];
-            nzbase += scan_tmp[32 + w];
+        // scan of the 1024 bin counts (one bin per thread) and of the non-empty flags; reservation of the tile's run
+        const uint32_t c = lhist[tid];
+        uint32_t incl = c;
+        incl = wave_scan_incl(incl);
+        const unsigned long long nzb = __ballot(c != 0);
+        if (lane == 63) scan_tmp[wave] = incl | ((uint32_t)__popcll(nzb) << 16);  // records < 2^16, non-empty bins <= 1024
+        __syncthreads();
+        uint32_t before, total;
+        wave_totals<NT / 64>(scan_tmp, lane, wave, before, total);
+        const uint32_t staged = total & 0xFFFFu;
+        const uint32_t ex = (before & 0xFFFFu) + incl - c;
+        const uint32_t myr = (before >> 16) + (uint32_t)__popcll(nzb & ((1ull << lane) - 1ull));
+        lstart[tid] = ex;
+        uint32_t greserve = 0;
+        if (c) {
+            greserve = atomicAdd(&cursor[(tid << L.xcd_shift) + xcc], c);
+            nz[myr] = (uint16_t)tid;
+            atomicOr(&mark[ex >> 6], 1ull << (ex & 63u));
         }
-        staged += scan_tmp[w];
-    }
-    const uint32_t ex = wb + incl - c;
-    lstart[tid] = ex;
-    uint32_t greserve = 0;
-    if (c) {
-        greserve = atomicAdd(&cursor[(tid << L.xcd_shift) + xcc], c);
-        nz[nzbase + (uint32_t)__popcll(nzb & ((1ull << lane) - 1ull))] = (uint16_t)tid;
-        atomicOr(&mark[ex >> 6], 1ull << (ex & 63u));
-    }
-    __syncthreads();
-    BBK_PH(5, 2, t_prev);  // scans + reservation issue + marks
+        __syncthreads();  // (every thread has read its count: lhist may become the table)
+        BBK_PH(5, 2, t_prev);  // scans + reservation issue + marks
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        if (binrank[i] != 0xFFFFFFFFu) {
-            const uint32_t pos = lstart[(binrank[i] >> 14) & 1023u] + (binrank[i] & 0x3FFFu);
-            stage[pos] = lo[i];
-            if (HAS_VAL) vstage[pos] = (uint8_t)(binrank[i] >> 24);
-        }
-    }
-    goff[tid] = greserve - ex;
-    {
-        // first staged position of this bin that no longer fits its slot
-        const uint64_t slot_end = L.xcd_shift ? (uint64_t)tid * L.slot_stride + (uint64_t)(xcc + 1u) * L.sub_cap
-                                              : (uint64_t)tid * L.slot_stride + L.slot_cap;
-        const int64_t room = (int64_t)slot_end - (int64_t)greserve;
-        lhist[tid] = (uint32_t)(int32_t)(room < -(int64_t)0x7FFF0000 ? -(int64_t)0x7FFF0000 : room) + ex;
-    }
-    if (wave == 0) {  // marks before every 64-position word: lane l owns words WPL*l .. WPL*l + WPL-1
-        constexpr int WPL = (MW + 63) / 64;
-        uint32_t p[WPL], tot = 0;
-#pragma unroll
-        for (int j = 0; j < WPL; ++j) {
-            const int idx = lane * WPL + j;
-            p[j] = tot;
-            tot += idx < MW ? (uint32_t)__popcll(mark[idx]) : 0u;
-        }
-        uint32_t inc2 = tot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(inc2, d, 64);
-            if (lane >= d) inc2 += t;
-        }
-        const uint32_t lb = inc2 - tot;
-#pragma unroll
-        for (int j = 0; j < WPL; ++j) {
-            const int idx = lane * WPL + j;
-            if (idx < MW) mbase[idx] = (uint16_t)(lb + p[j]);
-        }
-    }
-    __syncthreads();
-    BBK_PH(5, 3, t_prev);  // reorder into LDS + mark prefix
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t pos = (uint32_t)i * NT + tid;
-        if (pos < staged) {
-            const uint32_t w = pos >> 6;  // uniform in the wave: its 64 lanes cover one mark word
-            const uint32_t r = (uint32_t)mbase[w] + (uint32_t)__popcll(mark[w] & ((2ull << lane) - 1ull)) - 1u;
-            const uint32_t b = nz[r];
-            const uint32_t rec = stage[pos];
-            if ((int32_t)pos >= (int32_t)lhist[b]) {
-                const uint32_t sp = atomicAdd(L.spill_count, 1u);
-                if (sp < L.spill_cap) {
-                    reinterpret_cast<uint64_t *>(L.spill_keys)[sp] = nw_key(b, rec, hb);
-                    if (HAS_VAL) L.spill_vals[sp] = vstage[pos];
-                }
-            } else {
-                const uint32_t g = goff[b] + pos;
-                out[g] = rec;
-                if (HAS_VAL) vout[g] = vstage[pos];
+        for (int i = 0; i < ITEMS; ++i) {
+            const int r = i / CH, j = i % CH;
+            if ((uint32_t)j < ((cnts >> (4 * r)) & 15u)) {
+                const uint32_t bin = (bins[r * 3 + j / 3] >> (10 * (j % 3))) & 1023u;
+                const uint32_t pos = atomicAdd(&lstart[bin], 1u);  // (lstart ends as the bins' end offsets; nothing reads it again)
+                stage[pos] = lo[i];
+                if (HAS_VAL) vstage[pos] = (uint8_t)(masks[r * 2 + (j >> 2)] >> (8 * (j & 3)));
             }
         }
-    }
-    BBK_PH(5, 4, t_prev);  // store issue
+        asm volatile("" : "+v"(greserve));  // awaited by every lane here, not inside the store loop's conditional blocks
+        if (c) {
+            // first staged position of this bin that no longer fits its slot
+            const uint64_t slot_end = L.xcd_shift ? (uint64_t)tid * L.slot_stride + (uint64_t)(xcc + 1u) * L.sub_cap
+                                                  : (uint64_t)tid * L.slot_stride + L.slot_cap;
+            const int64_t room = (int64_t)slot_end - (int64_t)greserve;
+            tab[myr] = make_uint2(greserve - ex,
+                                  (uint32_t)(int32_t)(room < -(int64_t)0x7FFF0000 ? -(int64_t)0x7FFF0000 : room) + ex);
+        }
+        if (wave == 0) {  // marks before every 64-position word: lane l owns words WPL*l .. WPL*l + WPL-1
+            constexpr int WPL = (MW + 63) / 64;
+            uint32_t pw[WPL], tot = 0;
+#pragma unroll
+            for (int j = 0; j < WPL; ++j) {
+                const int idx = lane * WPL + j;
+                pw[j] = tot;
+                tot += idx < MW ? (uint32_t)__popcll(mark[idx]) : 0u;
+            }
+            uint32_t inc2 = tot;
+            inc2 = wave_scan_incl(inc2);
+            const uint32_t lb = inc2 - tot;
+#pragma unroll
+            for (int j = 0; j < WPL; ++j) {
+                const int idx = lane * WPL + j;
+                if (idx < MW) mbase[idx] = (uint16_t)(lb + pw[j]);
+            }
+        }
+        __syncthreads();
+        BBK_PH(5, 3, t_prev);  // reorder into LDS + mark prefix
+        if (more) prefetch(Tn, Q);  // in flight during the stores below
+        else Q = Pre{0, 0, 0, 0, 0};   // (the old values end here either way: they must not stay alive through the loop)
+        const unsigned long long upto = (2ull << lane) - 1ull;  // this lane and the ones below
+        // pos = i * NT + tid: the 64 lanes of a wave cover mark word i * (NT / 64) + wave
+        const unsigned long long *wmark = mark + wave;
+        const uint16_t *wmbase = mbase + wave;
+        uint32_t full = 0;  // items whose slot is full (rare; handled after the stores so that no atomic sits between them)
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t pos = (uint32_t)i * NT + tid;
+            if (pos < staged) {
+                const uint32_t r = (uint32_t)wmbase[i * (NT / 64)] + (uint32_t)__popcll(wmark[i * (NT / 64)] & upto) - 1u;
+                unsigned long long e = reinterpret_cast<const unsigned long long *>(tab)[r];
+                const uint32_t rec = stage[pos];
+                asm volatile("" : "+v"(e));  // one 8-byte LDS read (otherwise: the limit, a branch, then the offset)
+                if ((int32_t)pos >= (int32_t)(uint32_t)(e >> 32)) {
+                    full |= 1u << i;
+                } else {
+                    const uint32_t g = (uint32_t)e + pos;
+                    out[g] = rec;
+                    if (HAS_VAL) vout[g] = vstage[pos];
+                }
+            }
+        }
+        if (full) {
+#pragma unroll 1
+            for (int i = 0; i < ITEMS; ++i) {
+                if ((full >> i) & 1u) {
+                    const uint32_t pos = (uint32_t)i * NT + tid;
+                    const uint32_t r = (uint32_t)wmbase[i * (NT / 64)] + (uint32_t)__popcll(wmark[i * (NT / 64)] & upto) - 1u;
+                    const uint32_t sp = atomicAdd(L.spill_count, 1u);
+                    if (sp < L.spill_cap) {
+                        reinterpret_cast<uint64_t *>(L.spill_keys)[sp] = nw_key(nz[r], stage[pos], hb);
+                        if (HAS_VAL) L.spill_vals[sp] = vstage[pos];
+                    }
+                }
+            }
+        }
+        BBK_PH(5, 4, t_prev);  // store issue
 #ifdef BBK_PHASE_PROF
-    if (threadIdx.x == 0) atomicAdd(&g_phase[5][7], 1ull);
+        if (threadIdx.x == 0) atomicAdd(&g_phase[5][7], 1ull);
 #endif
+        if (!more) break;
+        __syncthreads();  // the stage and the tables have been read: the next tile may overwrite them
+        tile = tile_next;
+        T = Tn;
+    }
 }
 
 static size_t part_reads_narrow_smem(bool has_val) {
@@ -2110,6 +2235,7 @@ __global__ __launch_bounds__(kNw2Threads) void k_part_narrow2(const uint32_t *__
     const int hb = L.narrow_hb;
     const uint4 d = desc[blockIdx.x];  // first record, records, bins of the segment | segment << 16, flat index of bin 0
     const uint32_t begin = d.x, count = d.y, nb = d.z & 0xFFFFu, seg = d.z >> 16, gbin0 = d.w;
+    if (count == 0) return;  // an unused place of the XCD-wise order (k_tile_desc_narrow)
     lhist[tid] = 0;  // NT == MAXB
     __syncthreads();
     uint32_t lo[ITEMS], vals[ITEMS], binrank[ITEMS];
@@ -2130,7 +2256,7 @@ __global__ __launch_bounds__(kNw2Threads) void k_part_narrow2(const uint32_t *__
         const uint32_t local = (uint32_t)i * NT + tid;
         binrank[i] = 0xFFFFFFFFu;
         if (local < count) {
-            const uint32_t b = __umulhi(nw_p2(nw_mix(lo[i]), hb), nb);
+            const uint32_t b = __umulhi(nw_p2(nw_mix(lo[i])), nb);
             const uint32_t rank = atomicAdd(&lhist[b], 1u);
             binrank[i] = (b << 16) | rank;
         }
@@ -2139,22 +2265,18 @@ __global__ __launch_bounds__(kNw2Threads) void k_part_narrow2(const uint32_t *__
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t c = tid < nb ? lhist[tid] : 0u;
     uint32_t incl = c;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const uint32_t t = __shfl_up(incl, dd, 64);
-        if (lane >= dd) incl += t;
-    }
+    incl = wave_scan_incl(incl);
     if (lane == 63) scan_tmp[wave] = incl;
     __syncthreads();
-    uint32_t wb = 0, staged = 0;
-    for (int w = 0; w < NT / 64; ++w) {
-        if (w < wave) wb += scan_tmp[w];
-        staged += scan_tmp[w];
-    }
+    uint32_t wb, staged;
+    wave_totals<NT / 64>(scan_tmp, lane, wave, wb, staged);
     const uint32_t ex = wb + incl - c;
     if (tid < nb) lstart[tid] = ex;
-    const uint32_t greserve = c ? atomicAdd(&cursor[gbin0 + tid], c) : 0u;
+    uint32_t greserve = c ? atomicAdd(&cursor[gbin0 + tid], c) : 0u;
     __syncthreads();
+    // the reservation's result is awaited HERE, by every lane: the compiler otherwise puts the wait for it (vmcnt 0) into
+    // the conditional blocks of the store loop below, where it makes every store wait for the one before
+    asm volatile("" : "+v"(greserve));
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         if (binrank[i] != 0xFFFFFFFFu) {
@@ -2169,22 +2291,34 @@ __global__ __launch_bounds__(kNw2Threads) void k_part_narrow2(const uint32_t *__
         lhist[tid] = (uint32_t)(int32_t)(room < -(int64_t)0x7FFF0000 ? -(int64_t)0x7FFF0000 : room) + ex;
     }
     __syncthreads();
+    // (records whose slot is full are rare and handled after the stores: the spill counter's atomic returns a value, and
+    // a wait for it between the stores would make every store wait for the one before)
+    uint32_t full = 0;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t pos = (uint32_t)i * NT + tid;
         if (pos < staged) {
             const uint32_t rec = stage[pos];
-            const uint32_t b = __umulhi(nw_p2(nw_mix(rec), hb), nb);
+            const uint32_t b = __umulhi(nw_p2(nw_mix(rec)), nb);
             if ((int32_t)pos >= (int32_t)lhist[b]) {
-                const uint32_t sp = atomicAdd(L.spill_count, 1u);
-                if (sp < L.spill_cap) {
-                    reinterpret_cast<uint64_t *>(L.spill_keys)[sp] = nw_key(seg, rec, hb);
-                    if (HAS_VAL) L.spill_vals[sp] = vstage[pos];
-                }
+                full |= 1u << i;
             } else {
                 const uint32_t g = goff[b] + pos;
                 out[g] = rec;
                 if (HAS_VAL) vout[g] = vstage[pos];
+            }
+        }
+    }
+    if (full) {
+#pragma unroll 1
+        for (int i = 0; i < ITEMS; ++i) {
+            if ((full >> i) & 1u) {
+                const uint32_t pos = (uint32_t)i * NT + tid;
+                const uint32_t sp = atomicAdd(L.spill_count, 1u);
+                if (sp < L.spill_cap) {
+                    reinterpret_cast<uint64_t *>(L.spill_keys)[sp] = nw_key(seg, stage[pos], hb);
+                    if (HAS_VAL) L.spill_vals[sp] = vstage[pos];
+                }
             }
         }
     }
@@ -2195,8 +2329,13 @@ static size_t part_narrow2_smem(bool has_val) {
 }
 
 // level-2 tile descriptors of the narrow path: like k_tile_desc, with the segment id beside the bin count
+// xstart (optional): the tiles of level-1 segment s are dealt to the workgroups that run on XCD s % 8 (workgroup b runs on
+// XCD b % 8): tile i of M-entry e becomes workgroup 8 * (xstart[e] + i) + s % 8.  All tiles that fill the buckets of one
+// segment then write through ONE L2 (lines filled from several XCDs are what makes a scatter slow, see the level-1 call
+// site), and few segments are in flight per XCD at a time.  Unused places keep a zero descriptor (no records).
 __global__ void k_tile_desc_narrow(TileMap M, const uint32_t *__restrict__ seg_nb2, const uint32_t *__restrict__ seg_bin_start,
-                                   uint32_t tile_size, int sub_shift, uint4 *__restrict__ desc) {
+                                   uint32_t tile_size, int sub_shift, const uint32_t *__restrict__ xstart,
+                                   uint4 *__restrict__ desc) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M.ntiles) return;
     uint32_t lo = 0, hi = M.nseg;
@@ -2208,7 +2347,8 @@ __global__ void k_tile_desc_narrow(TileMap M, const uint32_t *__restrict__ seg_n
     const uint32_t b = M.seg_off[lo] + (t - M.seg_tile_start[lo]) * tile_size;
     const uint32_t e = M.seg_off[lo] + M.seg_size[lo];
     const uint32_t seg = lo >> sub_shift;  // M's entries are the per-XCD sub-slots of the level-1 segments
-    desc[t] = make_uint4(b, (e - b) < tile_size ? (e - b) : tile_size, seg_nb2[seg] | (seg << 16), seg_bin_start[seg]);
+    const uint32_t at = xstart ? 8u * (xstart[lo] + (t - M.seg_tile_start[lo])) + (seg & 7u) : t;
+    desc[at] = make_uint4(b, (e - b) < tile_size ? (e - b) : tile_size, seg_nb2[seg] | (seg << 16), seg_bin_start[seg]);
 }
 
 // Dedup of one bucket of 4-byte records in an LDS table (32-bit ds_cmpst); the distinct records leave as 8-byte keys
@@ -2292,24 +2432,20 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(const uint32_t
 #pragma unroll
     for (int j = 0; j < SPT; ++j) cnt += tab[j * kNwHashThreads + tid] != EMPTY ? 1u : 0u;
     uint32_t incl = cnt;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const uint32_t t = __shfl_up(incl, dd, 64);
-        if (lane >= dd) incl += t;
-    }
+    incl = wave_scan_incl(incl);
     if (lane == 63) scan_tmp[wave] = incl;
     __syncthreads();
-    uint32_t wbase = 0, total = 0;
-    for (int j = 0; j < kNwHashThreads / 64; ++j) {
-        if (j < wave) wbase += scan_tmp[j];
-        total += scan_tmp[j];
-    }
+    uint32_t seg = bucket_seg[b];
+    uint32_t wbase, total;
+    wave_totals<kNwHashThreads / 64>(scan_tmp, lane, wave, wbase, total);
     const uint32_t extra = scan_tmp[13] ? 1u : 0u;
     if (tid == 0) scan_tmp[15] = atomicAdd(A.out_total, total + extra);
     __syncthreads();
+    // (the segment id is awaited here by every lane, not inside the conditional blocks of the store loop, where the
+    // wait -- vmcnt 0 -- would make every store wait for the one before)
+    asm volatile("" : "+v"(seg));
     const uint32_t obase = scan_tmp[15];
     uint64_t *okeys = reinterpret_cast<uint64_t *>(A.out_keys);
-    const uint32_t seg = bucket_seg[b];
     uint32_t o = obase + wbase + incl - cnt;
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
@@ -2558,15 +2694,18 @@ struct MsdRunner {
         const int w0bits = (W == 1) ? (int)(2 * k) : 64;
 
         // ---- instance space (reads: k-mers for the sizes, chunks for the level-1 tiles)
-        DevBuf coff, tile_read;
+        DevBuf coff, tile_read, unordered;
         uint64_t N = (expand_k && rd == nullptr) ? 2 * n_in : n_in, n_chunks = 0;
         if (from_reads) {
             BBK_REQUIRE(dmode == MSD_HASH, BBK_ERR_INTERNAL, "reads are partitioned by hash prefix only");
             DevBuf nk((rd->n + 1) * sizeof(uint64_t));
             coff.alloc((rd->n + 1) * sizeof(uint64_t));
+            unordered.alloc(16);
+            BBK_HIP(hipMemsetAsync(unordered.p, 0, 16, ctx->stream));
             if (rd->n) {
                 hipLaunchKernelGGL(k_kmers_per_read2, bbk::grid_blocks((rd->n + 255) / 256), dim3(256), 0, ctx->stream,
-                                   rd->d_len, rd->n, k, (uint32_t)RdCfg<W>::CH, nk.as<uint64_t>(), coff.as<uint64_t>());
+                                   rd->d_len, rd->d_woff, rd->n, k, (uint32_t)RdCfg<W>::CH, nk.as<uint64_t>(),
+                                   coff.as<uint64_t>(), unordered.as<uint32_t>());
                 check_launch("k_kmers_per_read2");
             }
             N = exclusive_scan_u64(ctx, nk.as<uint64_t>(), nk.as<uint64_t>(), rd->n);
@@ -2656,11 +2795,11 @@ struct MsdRunner {
                 hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1 + 255) / 256), dim3(256), 0, ctx->stream, coff.as<uint64_t>(),
                                    rd->d_woff, rd->d_len, rd->n, (uint64_t)ntiles1, rd_tile,
                                    (uint32_t)RdCfg<W>::CH, k, (uint32_t)kRdSlots, (uint32_t)kRdWords,
-                                   tile_read.as<RdTile>());
+                                   unordered.as<uint32_t>(), tile_read.as<RdTile>());
                 hipLaunchKernelGGL(k_tile_reads, dim3((ntiles1h + 255) / 256), dim3(256), 0, ctx->stream,
                                    coff.as<uint64_t>(), rd->d_woff, rd->d_len, rd->n, (uint64_t)ntiles1h,
                                    (uint32_t)kRdHistThreads, (uint32_t)RdCfg<W>::CH, k, (uint32_t)kRdSlots,
-                                   (uint32_t)kRdWords, tiles_h.as<RdTile>());
+                                   (uint32_t)kRdWords, unordered.as<uint32_t>(), tiles_h.as<RdTile>());
                 check_launch("k_tile_reads");
             }
             S = ReadSrc{rd->d_words, rd->d_woff, rd->d_len, coff.as<uint64_t>(), tile_read.as<RdTile>(), rd->n, n_chunks,
@@ -2693,12 +2832,13 @@ struct MsdRunner {
         const bool slots = hslots || kslots;
         BBK_REQUIRE(!narrow || slots, BBK_ERR_INTERNAL, "narrow records need the slot mode");
         // narrow level 1: one sub-slot (and cursor) per XCD inside every segment slot (PartLevel::xcd_shift); the XCDs do
-        // not take exactly equal shares of the tiles, so the sub-slots get 6 % + 2048 records of slack
-        // Measured (profiles/r03/xcd_slots_*): the level-1 kernel 3.96 -> 3.79 ms, but its HBM write traffic did NOT
-        // fall (7.7 -> 8.1 GB for 5.2 GB of records: the partial sectors are not merged in L2 either way), level 2 reads
-        // eight short runs per segment instead of one (2.62 -> 2.70 ms) and the step gains 0.1 ms of 15.3: withdrawn as
-        // the default, kept as an experiment (BBK_XCD_SLOTS=1).
-        static const bool use_xcd = getenv("BBK_XCD_SLOTS") != nullptr;
+        // not take exactly equal shares of the tiles, so the sub-slots get 6 % + 2048 records of slack.
+        // A 128-byte line of a segment that workgroups on DIFFERENT XCDs fill (their ~60-byte runs are adjacent) is
+        // what makes this kernel's store pattern slow: tools/probes/reserve_scatter_probe.hip replays the pattern
+        // without any arithmetic -- 3.8 ms with one fill front per segment, 2.1 ms with one per (segment, XCD), 6.4 ms
+        // when adjacent runs ALWAYS come from different XCDs.  The kernel itself: 3.64 -> 2.94 ms (same call, round 3;
+        // in round 2 its arithmetic took as long as the stores and hid the gain: 3.96 -> 3.79).  BBK_XCD_SLOTS=0: A/B.
+        static const bool use_xcd = !(getenv("BBK_XCD_SLOTS") && atoi(getenv("BBK_XCD_SLOTS")) == 0);
         const int xs = (narrow && use_xcd) ? 3 : 0;
         const uint32_t nsub = nb1 << xs;  // level-1 cursors = level-2 input segments
         const uint32_t sub_cap = xs ? ((uint32_t)((double)N / nsub * 1.06) + 2048u) | 1u : 0u;
@@ -2780,15 +2920,22 @@ struct MsdRunner {
                 if constexpr (W == 1) {
                     const double pbn = (double)rd->n_words * 8 + (double)N * (4 + (has_val ? 4 : 0));
                     const size_t sm = part_reads_narrow_smem(has_val);
+                    // One tile per workgroup.  The kernel can also run as persistent workgroups that walk every grid-th
+                    // tile and load the next tile's tables during the stores of the current one
+                    // (BBK_NW_WGS_PER_CU=2): measured slower in the same call, 3.38-3.46 ms against 2.94 -- the wait
+                    // for the loaded tables at the top of the loop is also a wait for the tile's stores, and the
+                    // hardware dispatcher balances the tiles better than a static stride.
+                    static const uint32_t per_cu = getenv("BBK_NW_WGS_PER_CU") ? (uint32_t)atoi(getenv("BBK_NW_WGS_PER_CU")) : 0u;
+                    const uint32_t grid = per_cu ? std::min<uint32_t>(ntiles1, (uint32_t)ctx->num_cus * per_cu) : ntiles1;
                     KernelTimer t(ctx, "k_part_reads_narrow", pbn);
                     if (has_val) {
                         auto fn = k_part_reads_narrow<true>;
                         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-                        hipLaunchKernelGGL(fn, dim3(ntiles1), dim3(kNwThreads), sm, ctx->stream, S, L1, cur1.as<uint32_t>(), bufA.as<uint32_t>(), valA.as<uint32_t>());
+                        hipLaunchKernelGGL(fn, dim3(grid), dim3(kNwThreads), sm, ctx->stream, S, L1, ntiles1, cur1.as<uint32_t>(), bufA.as<uint32_t>(), valA.as<uint32_t>());
                     } else {
                         auto fn = k_part_reads_narrow<false>;
                         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-                        hipLaunchKernelGGL(fn, dim3(ntiles1), dim3(kNwThreads), sm, ctx->stream, S, L1, cur1.as<uint32_t>(), bufA.as<uint32_t>(), (uint32_t *)nullptr);
+                        hipLaunchKernelGGL(fn, dim3(grid), dim3(kNwThreads), sm, ctx->stream, S, L1, ntiles1, cur1.as<uint32_t>(), bufA.as<uint32_t>(), (uint32_t *)nullptr);
                     }
                     check_launch("k_part_reads_narrow");
                 }
@@ -2876,11 +3023,31 @@ struct MsdRunner {
         PartLevel L2{2, b1, nb1, dmode, w0bits, seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), sel.lo, sel.span, sel.shl, sel.mul};
         const uint32_t ntiles2 = tstart[nsub];
         TileMap M2{seg_tile.as<uint32_t>(), seg_off.as<uint32_t>(), seg_size.as<uint32_t>(), nsub, N, ntiles2, 1, nullptr, 0, 0};
-        DevBuf desc2((size_t)ntiles2 * sizeof(uint4) + 16);
+        // narrow level 2: workgroups dealt to the XCDs by segment (k_tile_desc_narrow); BBK_XCD_TILES=0: A/B
+        static const bool xcd_tiles = !(getenv("BBK_XCD_TILES") && atoi(getenv("BBK_XCD_TILES")) == 0);
+        uint32_t nwg2 = ntiles2;  // workgroups of the level-2 kernel
+        DevBuf xstart_d;
+        if (narrow && xcd_tiles && ntiles2) {
+            std::vector<uint32_t> xstart(nsub);
+            uint32_t per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t s2 = 0; s2 < nsub; ++s2) {
+                uint32_t &c = per_xcd[(s2 >> xs) & 7u];
+                xstart[s2] = c;
+                c += tstart[s2 + 1] - tstart[s2];
+            }
+            nwg2 = 8u * *std::max_element(per_xcd, per_xcd + 8);
+            xstart_d.alloc((size_t)nsub * 4);
+            BBK_HIP(hipMemcpyAsync(xstart_d.p, xstart.data(), (size_t)nsub * 4, hipMemcpyHostToDevice, ctx->stream));
+            BBK_HIP(hipStreamSynchronize(ctx->stream));  // xstart is a local
+        }
+        DevBuf desc2((size_t)nwg2 * sizeof(uint4) + 16);
         if (ntiles2) {
-            if (narrow)
+            if (narrow) {
+                if (xstart_d.p) BBK_HIP(hipMemsetAsync(desc2.p, 0, (size_t)nwg2 * sizeof(uint4), ctx->stream));
                 hipLaunchKernelGGL(k_tile_desc_narrow, dim3((ntiles2 + 255) / 256), dim3(256), 0, ctx->stream, M2,
-                                   seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), tile2, xs, desc2.as<uint4>());
+                                   seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), tile2, xs,
+                                   (const uint32_t *)xstart_d.p, desc2.as<uint4>());
+            }
             else
                 hipLaunchKernelGGL(k_tile_desc, dim3((ntiles2 + 255) / 256), dim3(256), 0, ctx->stream, M2, seg_nb2.as<uint32_t>(),
                                    seg_bin.as<uint32_t>(), kPartTileK, desc2.as<uint4>());
@@ -2928,12 +3095,12 @@ struct MsdRunner {
                 if (has_val) {
                     auto fn = k_part_narrow2<true>;
                     BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-                    hipLaunchKernelGGL(fn, dim3(ntiles2), dim3(kNw2Threads), sm, ctx->stream, bufA.as<uint32_t>(), valA.as<uint32_t>(),
+                    hipLaunchKernelGGL(fn, dim3(nwg2), dim3(kNw2Threads), sm, ctx->stream, bufA.as<uint32_t>(), valA.as<uint32_t>(),
                                        desc2.as<uint4>(), L2, hist2.as<uint32_t>(), bufB.as<uint32_t>(), valB.as<uint32_t>());
                 } else {
                     auto fn = k_part_narrow2<false>;
                     BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-                    hipLaunchKernelGGL(fn, dim3(ntiles2), dim3(kNw2Threads), sm, ctx->stream, bufA.as<uint32_t>(), (const uint32_t *)nullptr,
+                    hipLaunchKernelGGL(fn, dim3(nwg2), dim3(kNw2Threads), sm, ctx->stream, bufA.as<uint32_t>(), (const uint32_t *)nullptr,
                                        desc2.as<uint4>(), L2, hist2.as<uint32_t>(), bufB.as<uint32_t>(), (uint32_t *)nullptr);
                 }
                 check_launch("k_part_narrow2");

@@ -475,6 +475,12 @@ __global__ __launch_bounds__(kSk2NT) void k_sk_part2(const uint64_t *__restrict_
     }
     if (HIST) return;
     __syncthreads();
+    // (the records are awaited here by every lane: left to the compiler, the wait for the predicated loads -- vmcnt 0 --
+    // lands in the conditional blocks of the store loop and makes every store wait for the one before)
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+#pragma unroll
+        for (int j = 0; j < RW; ++j) asm volatile("" : "+v"(rec[i][j]));
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         if (binrank[i] == 0xFFFFFFFFu) continue;
