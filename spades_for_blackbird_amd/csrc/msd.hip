@@ -259,7 +259,8 @@ struct TileMap {
 
 // level 2: tile -> descriptor (one thread per tile)
 __global__ void k_tile_desc(TileMap M, const uint32_t *__restrict__ seg_nb2, const uint32_t *__restrict__ seg_bin_start,
-                            uint32_t tile_size, uint4 *__restrict__ desc) {
+                            uint32_t tile_size, int sub_shift, const uint32_t *__restrict__ xstart,
+                            uint4 *__restrict__ desc) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M.ntiles) return;
     uint32_t lo = 0, hi = M.nseg;  // largest s with seg_tile_start[s] <= t
@@ -270,7 +271,11 @@ __global__ void k_tile_desc(TileMap M, const uint32_t *__restrict__ seg_nb2, con
     }
     const uint32_t b = M.seg_off[lo] + (t - M.seg_tile_start[lo]) * tile_size;
     const uint32_t e = M.seg_size ? M.seg_off[lo] + M.seg_size[lo] : M.seg_off[lo + 1];
-    desc[t] = make_uint4(b, (e - b) < tile_size ? (e - b) : tile_size, seg_nb2[lo], seg_bin_start[lo]);
+    // M's entries are the level-1 segments or their per-XCD sub-slots (sub_shift); xstart: the tiles of a segment go to
+    // the workgroups of one XCD (see k_tile_desc_narrow)
+    const uint32_t seg = lo >> sub_shift;
+    const uint32_t at = xstart ? 8u * (xstart[lo] + (t - M.seg_tile_start[lo])) + (seg & 7u) : t;
+    desc[at] = make_uint4(b, (e - b) < tile_size ? (e - b) : tile_size, seg_nb2[seg], seg_bin_start[seg]);
 }
 
 struct TileInfo {
@@ -359,6 +364,12 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
     (void)prof_kind;
     (void)t_prev;
     uint32_t staged = 0;
+    // level 1 in slot mode: one fill front (cursor and sub-slot) per (segment, XCD), see PartLevel::xcd_shift
+    uint32_t xcc = 0;
+    if (L.xcd_shift) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= (1u << L.xcd_shift) - 1u;
+    }
     constexpr int BPT = (MAXB + THREADS - 1) / THREADS;
     uint32_t greserve[BPT], cq[BPT], ex0 = 0;
     {
@@ -386,7 +397,7 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
             const uint32_t bq = BPT * tid + q;
             if (bq < nb) lstart[bq] = ex;
             // the reservation is issued now and consumed after the LDS reorder: its latency overlaps that phase
-            greserve[q] = (bq < nb && c[q]) ? atomicAdd(&cursor[gbin0 + bq], c[q]) : 0u;
+            greserve[q] = (bq < nb && c[q]) ? atomicAdd(&cursor[((gbin0 + bq) << L.xcd_shift) + xcc], c[q]) : 0u;
             ex += c[q];
         }
     }
@@ -414,7 +425,9 @@ __device__ __forceinline__ void part_tail(const Key<W> (&keys)[ITEMS], const uin
                 goff[bq] = greserve[q] - ex;
                 if (L.slot_cap) {
                     // first staged position of this bin that no longer fits its slot (lhist is free by now)
-                    const int64_t room = (int64_t)((gbin0 + bq) * (uint64_t)L.slot_stride + L.slot_cap) - (int64_t)greserve[q];
+                    const uint64_t slot_end = (gbin0 + bq) * (uint64_t)L.slot_stride +
+                                              (L.xcd_shift ? (uint64_t)(xcc + 1u) * L.sub_cap : (uint64_t)L.slot_cap);
+                    const int64_t room = (int64_t)slot_end - (int64_t)greserve[q];
                     lhist[bq] = (uint32_t)(int32_t)(room < -(int64_t)0x7FFF0000 ? -(int64_t)0x7FFF0000 : room) + ex;
                 }
             }
@@ -600,6 +613,7 @@ __global__ __launch_bounds__(PartCfg<W>::THREADS) void k_part(const Key<W> *__re
     const TileInfo T = tile_info(M, L, blockIdx.x, (uint32_t)kPartTile);
     const uint64_t begin = T.begin, gbin0 = T.gbin0;  // gbin0: flat index of bin 0 in the cursor array
     const uint32_t count = T.count, nb = T.nb;
+    if (count == 0) return;  // an unused place of the XCD-wise order of level-2 tiles (k_tile_desc)
 
     for (uint32_t b = tid; b < nb; b += kPartThreads) lhist[b] = 0;
     __syncthreads();
@@ -2839,7 +2853,7 @@ struct MsdRunner {
         // when adjacent runs ALWAYS come from different XCDs.  The kernel itself: 3.64 -> 2.94 ms (same call, round 3;
         // in round 2 its arithmetic took as long as the stores and hid the gain: 3.96 -> 3.79).  BBK_XCD_SLOTS=0: A/B.
         static const bool use_xcd = !(getenv("BBK_XCD_SLOTS") && atoi(getenv("BBK_XCD_SLOTS")) == 0);
-        const int xs = (narrow && use_xcd) ? 3 : 0;
+        const int xs = (slots && use_xcd) ? 3 : 0;
         const uint32_t nsub = nb1 << xs;  // level-1 cursors = level-2 input segments
         const uint32_t sub_cap = xs ? ((uint32_t)((double)N / nsub * 1.06) + 2048u) | 1u : 0u;
         const uint32_t seg_cap = !slots ? 0u
@@ -3027,7 +3041,7 @@ struct MsdRunner {
         static const bool xcd_tiles = !(getenv("BBK_XCD_TILES") && atoi(getenv("BBK_XCD_TILES")) == 0);
         uint32_t nwg2 = ntiles2;  // workgroups of the level-2 kernel
         DevBuf xstart_d;
-        if (narrow && xcd_tiles && ntiles2) {
+        if (slots && xcd_tiles && ntiles2) {
             std::vector<uint32_t> xstart(nsub);
             uint32_t per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (uint32_t s2 = 0; s2 < nsub; ++s2) {
@@ -3048,9 +3062,11 @@ struct MsdRunner {
                                    seg_nb2.as<uint32_t>(), seg_bin.as<uint32_t>(), tile2, xs,
                                    (const uint32_t *)xstart_d.p, desc2.as<uint4>());
             }
-            else
+            else {
+                if (xstart_d.p) BBK_HIP(hipMemsetAsync(desc2.p, 0, (size_t)nwg2 * sizeof(uint4), ctx->stream));
                 hipLaunchKernelGGL(k_tile_desc, dim3((ntiles2 + 255) / 256), dim3(256), 0, ctx->stream, M2, seg_nb2.as<uint32_t>(),
-                                   seg_bin.as<uint32_t>(), kPartTileK, desc2.as<uint4>());
+                                   seg_bin.as<uint32_t>(), kPartTileK, xs, (const uint32_t *)xstart_d.p, desc2.as<uint4>());
+            }
             check_launch("k_tile_desc");
         }
         M2.desc = desc2.as<uint4>();
@@ -3107,8 +3123,8 @@ struct MsdRunner {
             }
         } else {
             const double pb = 2.0 * (double)N * (rec + (has_val ? 4 : 0));
-            if (has_val) launch_part<true, false>("k_part_l2", pb, ntiles2, bufA.as<Key<W>>(), valA.as<uint32_t>(), M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), valB.as<uint32_t>());
-            else launch_part<false, false>("k_part_l2", pb, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), nullptr);
+            if (has_val) launch_part<true, false>("k_part_l2", pb, nwg2, bufA.as<Key<W>>(), valA.as<uint32_t>(), M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), valB.as<uint32_t>());
+            else launch_part<false, false>("k_part_l2", pb, nwg2, bufA.as<Key<W>>(), nullptr, M2, L2, nullptr, hist2.as<uint32_t>(), bufB.as<Key<W>>(), nullptr);
         }
 
         // ---- buckets in LDS
