@@ -88,6 +88,12 @@ struct SkParams {
     uint32_t slot1;           // records of a level-1 slot
     uint32_t tps;             // level-2 tiles of a level-1 slot
     uint32_t spill_cap;       // records the level-1 spill list holds
+    uint32_t xcd_tiles;       // level 2: tiles dealt to the XCDs by slot (k_sk_part2)
+    // level 1: a slot is cut into 8 sub-slots of sub1 records, one per XCD, each with a cursor (cursor1[8 b + xcd]): the
+    // (tile, bin) runs are one to four 24-byte records, and a 128-byte line that workgroups on different XCDs fill is
+    // slow (msd.hip, level-1 call site).  0: one fill front per slot (slot1 = 8 * sub1 otherwise).
+    uint32_t sub1;
+    uint32_t tps_sub;         // level-2 tiles of a sub-slot (tps = 8 * tps_sub)
 };
 
 struct SkTile {
@@ -344,15 +350,22 @@ __global__ __launch_bounds__(kSk1NT) void k_sk_part1(SkReads S, SkParams P, uint
         }
     }
     __syncthreads();
+    uint32_t xcc = 0;  // the XCD this workgroup runs on (placement only: any value gives a correct result)
+    if (P.sub1) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+    }
+    const uint32_t cap1 = P.sub1 ? P.sub1 : P.slot1;  // records of the (sub-)slot this workgroup fills
+    const uint32_t sub_off = xcc * P.sub1;            // its place inside the slot
     for (uint32_t b = tid; b < P.P1; b += NT) {
         const uint32_t cb = lhist[b];
         uint32_t g = 0xFFFFFFFFu;
         if (cb) {
-            const uint32_t base = atomicAdd(&cursor1[b], cb);
-            if (base + cb <= P.slot1) {
+            const uint32_t base = atomicAdd(&cursor1[P.sub1 ? b * 8u + xcc : b], cb);
+            if (base + cb <= cap1) {
                 g = base;
             } else {  // what fits goes to the slot, the rest to the spill list
-                const uint32_t fit = base >= P.slot1 ? 0u : P.slot1 - base;
+                const uint32_t fit = base >= cap1 ? 0u : cap1 - base;
                 const uint32_t sb = atomicAdd(&flags[SKF_NSPILL], cb - fit);
                 const uint32_t idx = atomicAdd(&ovf_n, 1u);
                 if (idx < 64u && sb + (cb - fit) <= P.spill_cap) {
@@ -395,9 +408,10 @@ __global__ __launch_bounds__(kSk1NT) void k_sk_part1(SkReads S, SkParams P, uint
         uint64_t *dst;
         if (g & 0x80000000u) {
             const uint32_t *o = ovf[g & 63u];
-            dst = rank < o[1] ? out + ((uint64_t)b1 * P.slot1 + o[0] + rank) * RW : spill + ((uint64_t)o[2] + (rank - o[1])) * RW;
+            dst = rank < o[1] ? out + ((uint64_t)b1 * P.slot1 + sub_off + o[0] + rank) * RW
+                              : spill + ((uint64_t)o[2] + (rank - o[1])) * RW;
         } else {
-            dst = out + ((uint64_t)b1 * P.slot1 + g + rank) * RW;
+            dst = out + ((uint64_t)b1 * P.slot1 + sub_off + g + rank) * RW;
         }
 #pragma unroll
         for (int j = 0; j < RW; ++j) dst[j] = rec[j];
@@ -434,12 +448,27 @@ __global__ __launch_bounds__(kSk2NT) void k_sk_part2(const uint64_t *__restrict_
     __shared__ uint32_t lhist[kSkMaxP2];
     __shared__ unsigned long long gbase[HIST ? 1 : kSkMaxP2];
     const uint32_t tid = threadIdx.x;
-    const uint32_t b1 = blockIdx.x / P.tps, t = blockIdx.x % P.tps;
-    const uint32_t have = cursor1[b1];
-    const uint32_t cnt = have < P.slot1 ? have : P.slot1;
-    const uint32_t begin = t * (uint32_t)kSk2Tile;
-    if (begin >= cnt) return;
-    const uint32_t count = cnt - begin < (uint32_t)kSk2Tile ? cnt - begin : (uint32_t)kSk2Tile;
+    // Workgroup w runs on XCD w % 8: the tiles of slot b1 all go to XCD b1 % 8, so that the buckets of a slot are filled
+    // through ONE L2 (a line that several XCDs fill is slow: see the level-1 call site in msd.hip).  Grid: 8 *
+    // ceil(P1 / 8) * tps; BBK_XCD_TILES=0 (P.xcd_tiles = 0): slot-major order.
+    uint32_t b1, t;
+    if (P.xcd_tiles) {
+        const uint32_t j = blockIdx.x >> 3;
+        b1 = (j / P.tps) * 8u + (blockIdx.x & 7u);
+        t = j % P.tps;
+        if (b1 >= P.P1) return;
+    } else {
+        b1 = blockIdx.x / P.tps;
+        t = blockIdx.x % P.tps;
+    }
+    // tile t of the slot: tile t % tps_sub of sub-slot t / tps_sub when level 1 filled one sub-slot per XCD
+    const uint32_t sx = P.sub1 ? t / P.tps_sub : 0u, tt = P.sub1 ? t % P.tps_sub : t;
+    const uint32_t cap1 = P.sub1 ? P.sub1 : P.slot1;
+    const uint32_t have = cursor1[P.sub1 ? b1 * 8u + sx : b1];
+    const uint32_t cnt = have < cap1 ? have : cap1;
+    if (tt * (uint32_t)kSk2Tile >= cnt) return;
+    const uint32_t count = cnt - tt * (uint32_t)kSk2Tile < (uint32_t)kSk2Tile ? cnt - tt * (uint32_t)kSk2Tile : (uint32_t)kSk2Tile;
+    const uint32_t begin = sx * P.sub1 + tt * (uint32_t)kSk2Tile;  // first record of the tile inside the slot
     for (uint32_t b = tid; b < P.P2; b += NT) lhist[b] = 0;
     __syncthreads();
     const uint64_t *src = in + ((uint64_t)b1 * P.slot1 + begin) * RW;
@@ -1003,8 +1032,18 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     P.b1bits = b1bits;
     P.P1 = P1;
     P.P2 = P2;
-    P.slot1 = (uint32_t)slot1_64;
-    P.tps = (P.slot1 + kSk2Tile - 1) / kSk2Tile;
+    static const bool xcd_slots = !(getenv("BBK_XCD_SLOTS") && atoi(getenv("BBK_XCD_SLOTS")) == 0);
+    if (xcd_slots) {  // eight sub-slots, each with the slack of a slot of its size
+        P.sub1 = (uint32_t)((slot1_64 + 7) / 8) + (es1 ? 2u : 512u);
+        P.slot1 = 8u * P.sub1;
+        P.tps_sub = (P.sub1 + kSk2Tile - 1) / kSk2Tile;
+        P.tps = 8u * P.tps_sub;
+    } else {
+        P.sub1 = 0;
+        P.tps_sub = 0;
+        P.slot1 = (uint32_t)slot1_64;
+        P.tps = (P.slot1 + kSk2Tile - 1) / kSk2Tile;
+    }
     P.spill_cap = (uint32_t)std::min<double>(2.0e9, es1 ? est_pass + 65536.0 : est_pass / 8 + 65536.0);
     const uint64_t nbuckets = (uint64_t)P1 * P2;
     if ((uint64_t)P1 * P.tps >= (1ull << 31)) return false;
@@ -1027,7 +1066,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
 
     const size_t rec_bytes = (size_t)RW * 8;
     DevBuf buf1((size_t)P1 * P.slot1 * rec_bytes), buf2;
-    DevBuf cur1((size_t)P1 * 4 + 16), boff((size_t)(nbuckets + 1) * 8 + 16), cur2((size_t)nbuckets * 8 + 16), dflags(64),
+    DevBuf cur1((size_t)P1 * 8 * 4 + 16), boff((size_t)(nbuckets + 1) * 8 + 16), cur2((size_t)nbuckets * 8 + 16), dflags(64),
         dcursor(16), fail_list((size_t)kSkdFailCap * 4), fail2_list((size_t)kSkdFailCap * 4), hot, fb_total(16);
     DevBuf spill((size_t)P.spill_cap * rec_bytes + 16);
     // share of the instances the k-mer path may have to take over (hot buckets, spilled records) before the whole batch
@@ -1067,10 +1106,13 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
         ctx->superk_dup = 0;
         return false;
     };
+    static const bool xcd_tiles = !(getenv("BBK_XCD_TILES") && atoi(getenv("BBK_XCD_TILES")) == 0);
+    P.xcd_tiles = xcd_tiles ? 1u : 0u;
+    const uint32_t grid2 = xcd_tiles ? 8u * ((P1 + 7u) / 8u) * P.tps : P1 * P.tps;
     for (uint32_t pass = 0; pass < np; ++pass) {
         P.pass = pass;
         BBK_HIP(hipMemsetAsync(dflags.p, 0, 64, ctx->stream));
-        BBK_HIP(hipMemsetAsync(cur1.p, 0, (size_t)P1 * 4, ctx->stream));
+        BBK_HIP(hipMemsetAsync(cur1.p, 0, (size_t)P1 * 8 * 4, ctx->stream));
         BBK_HIP(hipMemsetAsync(boff.p, 0, (size_t)(nbuckets + 1) * 8, ctx->stream));
         {
             KernelTimer t(ctx, "k_sk_part1", (double)rd->n_words * 8 + est_pass * rec_bytes);
@@ -1080,7 +1122,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
         }
         {
             KernelTimer t(ctx, "k_sk_part2_hist", est_pass * rec_bytes);
-            hipLaunchKernelGGL((k_sk_part2<RW, true>), dim3(P1 * P.tps), dim3(kSk2NT), 0, ctx->stream, buf1.as<uint64_t>(), P,
+            hipLaunchKernelGGL((k_sk_part2<RW, true>), dim3(grid2), dim3(kSk2NT), 0, ctx->stream, buf1.as<uint64_t>(), P,
                                cur1.as<uint32_t>(), boff.as<unsigned long long>(), (uint64_t *)nullptr, dflags.as<uint32_t>());
             check_launch("k_sk_hist2");
         }
@@ -1106,7 +1148,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
         }
         {
             KernelTimer t(ctx, "k_sk_part2", 2.0 * (double)n_rec * rec_bytes);
-            hipLaunchKernelGGL((k_sk_part2<RW, false>), dim3(P1 * P.tps), dim3(kSk2NT), 0, ctx->stream, buf1.as<uint64_t>(), P,
+            hipLaunchKernelGGL((k_sk_part2<RW, false>), dim3(grid2), dim3(kSk2NT), 0, ctx->stream, buf1.as<uint64_t>(), P,
                                cur1.as<uint32_t>(), cur2.as<unsigned long long>(), buf2.as<uint64_t>(), dflags.as<uint32_t>());
             check_launch("k_sk_part2");
         }
