@@ -934,11 +934,9 @@ struct BucketArgs {
     // with the spill list
     uint32_t slot_cap, slot_stride;
     const uint32_t *cursor;
-    // hash-dedup kernels, unordered output: the distinct records go straight to out_keys/out_vals at a position
-    // reserved with one atomicAdd on out_total per bucket (no compaction pass); null: written back in place
-    void *out_keys;
-    uint32_t *out_vals;
-    uint32_t *out_total;
+    // (the hash-dedup kernels write the distinct records back to the head of their bucket; until round 3 they could also
+    // reserve a place in the dense result with an atomicAdd on one counter -- 2.6 ms for the 227 210 buckets of BASELINE
+    // configs[1], tools/probes/single_counter_probe.hip)
     // sorting kernels, input known to hold (almost certainly) no duplicates: bucket b's records go straight to
     // sorted_keys[boff[b] ...] (the dense result: same offsets as the input when nothing is removed), word 0 masked
     // with strip_mask; a bucket that did remove a duplicate raises *dup_flag and the caller redoes the pass in place
@@ -1624,16 +1622,9 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
     __syncthreads();
     uint32_t wbase, total;
     wave_totals<kHashThreads / 64>(scan_tmp, lane, wave, wbase, total);
-    Key<1> *obuf = buf;
+    Key<1> *obuf = buf;  // back to the head of the bucket (every record has been read before the barrier above)
     uint32_t *ovals = vals;
-    uint32_t obase = start;
-    if (A.out_keys) {  // dense unordered output: reserve this bucket's place
-        if (tid == 0) scan_tmp[15] = atomicAdd(A.out_total, total);  // slot 15: past the 8 wave totals
-        __syncthreads();
-        obase = scan_tmp[15];
-        obuf = reinterpret_cast<Key<1> *>(A.out_keys);
-        ovals = A.out_vals;
-    }
+    const uint32_t obase = start;
     uint32_t o = obase + wbase + incl - cnt;
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
@@ -1740,16 +1731,9 @@ __global__ __launch_bounds__(kHashIdxThreads) void k_bucket_hashidx(Key<W> *__re
     __syncthreads();
     uint32_t wbase, total;
     wave_totals<kHashIdxThreads / 64>(scan_tmp, lane, wave, wbase, total);
-    Key<W> *obuf = buf;
+    Key<W> *obuf = buf;  // back to the head of the bucket (every record has been read before the barrier above)
     uint32_t *ovals = vals;
-    uint32_t obase = start;
-    if (A.out_keys) {  // dense unordered output: reserve this bucket's place
-        if (tid == 0) scan_tmp[15] = atomicAdd(A.out_total, total);  // slot 15: past the 8 wave totals
-        __syncthreads();
-        obase = scan_tmp[15];
-        obuf = reinterpret_cast<Key<W> *>(A.out_keys);
-        ovals = A.out_vals;
-    }
+    const uint32_t obase = start;
     uint32_t o = obase + wbase + incl - cnt;
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
@@ -2373,8 +2357,8 @@ constexpr int kNwHashItems = 16;  // 8192 records per bucket
 constexpr uint32_t kNwHashSlots = 8192;
 
 template <int OP>
-__global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(const uint32_t *__restrict__ buf,
-                                                                 const uint32_t *__restrict__ vals, BucketArgs A,
+__global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(uint32_t *__restrict__ buf,
+                                                                 uint32_t *__restrict__ vals, BucketArgs A,
                                                                  const uint16_t *__restrict__ bucket_seg, int hb) {
     constexpr bool IN_VAL = OP >= 2;
     constexpr uint32_t EMPTY = 0xFFFFFFFFu;
@@ -2385,6 +2369,12 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(const uint32_t
                                                               // [13] its presence, [14] give-up flag, [15] output base
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
+#ifdef BBK_PHASE_PROF
+    unsigned long long t_prev = clock64();
+#else
+    const unsigned long long t_prev = 0;
+    (void)t_prev;
+#endif
     uint32_t start, n;
     bucket_range(A, b, &start, &n);
     if (n == 0) {
@@ -2401,6 +2391,7 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(const uint32_t
     }
     if (tid < 4) scan_tmp[12 + tid] = 0;
     __syncthreads();
+    BBK_PH(4, 0, t_prev);  // table cleared
     uint32_t kk[kNwHashItems], vv[kNwHashItems];
 #pragma unroll
     for (int i = 0; i < kNwHashItems; ++i) {
@@ -2409,6 +2400,11 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(const uint32_t
         kk[i] = buf[at];
         vv[i] = IN_VAL ? vals[at] : 0u;
     }
+#ifdef BBK_PHASE_PROF
+#pragma unroll
+    for (int i = 0; i < kNwHashItems; ++i) asm volatile("" : "+v"(kk[i]));
+    BBK_PH(4, 1, t_prev);  // records loaded
+#endif
 #pragma unroll
     for (int i = 0; i < kNwHashItems; ++i) {
         const uint32_t p = (uint32_t)(i * kNwHashThreads + tid);
@@ -2437,6 +2433,7 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(const uint32_t
         }
     }
     __syncthreads();
+    BBK_PH(4, 2, t_prev);  // inserted
     if (scan_tmp[14]) {  // the table is (nearly) full: nothing has been written, the caller takes over
         if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
         return;
@@ -2449,33 +2446,55 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(const uint32_t
     incl = wave_scan_incl(incl);
     if (lane == 63) scan_tmp[wave] = incl;
     __syncthreads();
-    uint32_t seg = bucket_seg[b];
     uint32_t wbase, total;
     wave_totals<kNwHashThreads / 64>(scan_tmp, lane, wave, wbase, total);
     const uint32_t extra = scan_tmp[13] ? 1u : 0u;
-    if (tid == 0) scan_tmp[15] = atomicAdd(A.out_total, total + extra);
-    __syncthreads();
-    // (the segment id is awaited here by every lane, not inside the conditional blocks of the store loop, where the
-    // wait -- vmcnt 0 -- would make every store wait for the one before)
-    asm volatile("" : "+v"(seg));
-    const uint32_t obase = scan_tmp[15];
-    uint64_t *okeys = reinterpret_cast<uint64_t *>(A.out_keys);
-    uint32_t o = obase + wbase + incl - cnt;
+    // The distinct records (4 bytes, still without their segment) go back to the head of the bucket's own slot; a
+    // pass over the bucket counts gives the offsets of the dense result and k_compact_narrow widens them into it.
+    // (Until round 3 every bucket reserved its place in the result with an atomicAdd on ONE counter: 227 210 buckets at
+    // BASELINE configs[1], served one after the other at ~11 ns each -- 2.6 ms of the kernel's 2.8,
+    // tools/probes/single_counter_probe.hip.)  Every record of the bucket has been read before the first barrier above.
+    uint32_t o = start + wbase + incl - cnt;
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
         const uint32_t rec = tab[j * kNwHashThreads + tid];
         if (rec != EMPTY) {
-            okeys[o] = nw_key(seg, rec, hb);
-            if (OP != 0) A.out_vals[o] = pay[j * kNwHashThreads + tid];
+            buf[o] = rec;
+            if (OP != 0) vals[o] = pay[j * kNwHashThreads + tid];
             ++o;
         }
     }
+    BBK_PH(4, 3, t_prev);  // compaction + output
+#ifdef BBK_PHASE_PROF
+    if (threadIdx.x == 0) atomicAdd(&g_phase[4][7], 1ull);
+#endif
     if (tid == 0) {
         if (extra) {
-            okeys[obase + total] = nw_key(seg, EMPTY, hb);
-            if (OP != 0) A.out_vals[obase + total] = scan_tmp[12];
+            buf[start + total] = EMPTY;
+            if (OP != 0) vals[start + total] = scan_tmp[12];
         }
         A.dcount[b] = total + extra;
+    }
+}
+
+// one wave per bucket of the narrow path: the distinct 4-byte records at the head of every bucket slot -> 8-byte keys
+// (nw_key: the segment gives the high bits) at their place in the dense result
+template <bool HAS_VAL>
+__global__ __launch_bounds__(256) void k_compact_narrow(const uint32_t *__restrict__ buf, const uint32_t *__restrict__ vals,
+                                                       const uint32_t *__restrict__ dcount, const uint64_t *__restrict__ doff,
+                                                       uint32_t nbuckets, uint32_t slot_stride,
+                                                       const uint16_t *__restrict__ bucket_seg, int hb,
+                                                       uint64_t *__restrict__ out, uint32_t *__restrict__ vout) {
+    const uint32_t b = (uint32_t)((BBK_GID()) >> 6);
+    if (b >= nbuckets) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t c = dcount[b];
+    if (c == 0xFFFFFFFFu) c = 0;  // left to the caller (reprocessed with the spill list)
+    const uint32_t s = b * slot_stride, seg = bucket_seg[b];
+    const uint64_t d = doff[b];
+    for (uint32_t i = lane; i < c; i += 64) {
+        out[d + i] = nw_key(seg, buf[s + i], hb);
+        if (HAS_VAL) vout[d + i] = vals[s + i];
     }
 }
 
@@ -3133,13 +3152,12 @@ struct MsdRunner {
         BBK_HIP(hipMemsetAsync(dbg.p, 0, 64, ctx->stream));
         // slot mode: the hash-dedup kernels write the distinct records straight into the (unordered) result
         const bool out_vals = op != MSD_OP_NONE;
-        if (hslots) {
-            out.keys.alloc((N + 16) * rec);  // upper bound; transient in every caller (expanded / exchanged next)
-            if (out_vals) out.vals.alloc((N + 16) * 4);
-        }
+        // (slot mode: the dedup kernels leave the distinct records at the head of every bucket slot, like the exact mode
+        // in its dense buckets; the compaction below makes the result.  BucketArgs::out_keys / out_total -- every bucket
+        // reserving its place in the result with an atomicAdd on one counter -- is no longer used: the counter served
+        // the 227 210 buckets of BASELINE configs[1] one after the other, 2.6 ms of 2.8.)
         BucketArgs A{boff.as<uint32_t>(), dcount.as<uint32_t>(), nullptr, (int)k, verbose ? dbg.as<uint32_t>() : nullptr,
-                     slots ? cap2 : 0u, slots ? stride2 : 0u, hist2.as<uint32_t>(), hslots ? out.keys.p : nullptr,
-                     hslots ? out.vals.as<uint32_t>() : nullptr, hslots ? spill_n.as<uint32_t>() + 1 : nullptr,
+                     slots ? cap2 : 0u, slots ? stride2 : 0u, hist2.as<uint32_t>(),
                      nullptr, nullptr, nullptr, ~0ull, hash_max_probes(), nullptr};
         const double bb = (double)N * (rec + (has_val ? 4 : 0));
         // Sorted output of a key array that should hold no duplicates (both strands of a distinct canonical set, odd
@@ -3354,7 +3372,7 @@ struct MsdRunner {
                     const uint32_t hbo[2] = {0u, (uint32_t)n_extra};
                     BBK_HIP(hipMemcpyAsync(tb.p, hbo, 8, hipMemcpyHostToDevice, ctx->stream));
                     BucketArgs At{tb.as<uint32_t>(), tc.as<uint32_t>(), nullptr, (int)k, nullptr, 0u, 0u,
-                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull, hash_max_probes(), nullptr};
+                                  nullptr, nullptr, nullptr, nullptr, ~0ull, hash_max_probes(), nullptr};
                     MsdRunner<W> sorter = *this;
                     sorter.dmode = MSD_KEYS;  // picks the sorting kernels in bucket_dispatch
                     sorter.expand_k = 0;
@@ -3406,7 +3424,7 @@ struct MsdRunner {
                 DevBuf ids(big.size() * 4);
                 BBK_HIP(hipMemcpyAsync(ids.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, ctx->stream));
                 BucketArgs A2{boff.as<uint32_t>(), dcount.as<uint32_t>(), ids.as<uint32_t>(), (int)k, nullptr, 0u, 0u,
-                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ~0ull, hash_max_probes(), nullptr};
+                              nullptr, nullptr, nullptr, nullptr, ~0ull, hash_max_probes(), nullptr};
                 const double b2 = (double)big_rec * (rec + (has_val ? 4 : 0));
                 bucket_dispatch<true>((uint32_t)big.size(), bufB.as<Key<W>>(), valB.as<uint32_t>(), A2, b2,
                                       /*allow_hash=*/false);
@@ -3453,37 +3471,50 @@ struct MsdRunner {
         }
         out.overflow_buckets = novf;
 
-        // ---- dense output.  Slot mode: already written by the dedup kernels (n_direct records, overflowing buckets
-        // wrote nothing; their records are in `extra`).  Exact mode: scan of the bucket counts + k_compact.
-        uint64_t D = n_direct;
+        // ---- dense output: scan of the bucket counts + compaction.  (Slot mode: overflowing buckets wrote nothing and
+        // count 0 here; their records are in `extra`, appended below.)
+        uint64_t D = 0;
         DevBuf d64;
-        if (slots) {
-            BBK_REQUIRE(D + extra.n <= N, BBK_ERR_INTERNAL, "more distinct records than records");
-            out.n = D + extra.n;
-        } else {
+        {
             d64.alloc(((size_t)nbuckets + 1) * 8);
             hipLaunchKernelGGL(k_u32_to_u64, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream,
                                dcount.as<uint32_t>(), (uint64_t)nbuckets, d64.as<uint64_t>(), 0u);
             check_launch("k_u32_to_u64");
             D = exclusive_scan_u64(ctx, d64.as<uint64_t>(), d64.as<uint64_t>(), nbuckets);
-            out.n = D;
+            if (slots) BBK_REQUIRE(D + extra.n <= N, BBK_ERR_INTERNAL, "more distinct records than records");
+            out.n = D + (slots ? extra.n : 0);
             if (!has_dst) {
                 out.keys.alloc(out.n * rec + 16);
                 if (out_vals) out.vals.alloc(out.n * 4 + 16);
             }
             Key<W> *ck = has_dst ? (Key<W> *)dst.keys : out.keys.as<Key<W>>();
             uint32_t *cv = has_dst ? dst.vals : out.vals.as<uint32_t>();
-            KernelTimer t(ctx, "compact", 2.0 * (double)D * (rec + (out_vals ? 4 : 0)));
+            const uint32_t *cboff = slots ? nullptr : boff.as<uint32_t>();  // slot mode: bucket b starts at b * stride2
             const unsigned blocks = (unsigned)(((uint64_t)nbuckets * 64 + 255) / 256);
-            if (out_vals)
-                hipLaunchKernelGGL((k_compact<W, true>), dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<Key<W>>(),
-                                   valB.as<uint32_t>(), boff.as<uint32_t>(), dcount.as<uint32_t>(), d64.as<uint64_t>(),
-                                   nbuckets, ck, cv, strip_mask, 0u);
-            else
-                hipLaunchKernelGGL((k_compact<W, false>), dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<Key<W>>(),
-                                   (const uint32_t *)nullptr, boff.as<uint32_t>(), dcount.as<uint32_t>(),
-                                   d64.as<uint64_t>(), nbuckets, ck, (uint32_t *)nullptr, strip_mask,
-                                   0u);
+            if (narrow) {
+                if constexpr (W == 1) {
+                    KernelTimer t(ctx, "compact", (double)D * (4 + 8 + (out_vals ? 8 : 0)));
+                    if (out_vals)
+                        hipLaunchKernelGGL(k_compact_narrow<true>, dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<uint32_t>(),
+                                           valB.as<uint32_t>(), dcount.as<uint32_t>(), d64.as<uint64_t>(), nbuckets, stride2,
+                                           bseg.as<uint16_t>(), nw_hb, reinterpret_cast<uint64_t *>(ck), cv);
+                    else
+                        hipLaunchKernelGGL(k_compact_narrow<false>, dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<uint32_t>(),
+                                           (const uint32_t *)nullptr, dcount.as<uint32_t>(), d64.as<uint64_t>(), nbuckets,
+                                           stride2, bseg.as<uint16_t>(), nw_hb, reinterpret_cast<uint64_t *>(ck),
+                                           (uint32_t *)nullptr);
+                }
+            } else {
+                KernelTimer t(ctx, "compact", 2.0 * (double)D * (rec + (out_vals ? 4 : 0)));
+                if (out_vals)
+                    hipLaunchKernelGGL((k_compact<W, true>), dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<Key<W>>(),
+                                       valB.as<uint32_t>(), cboff, dcount.as<uint32_t>(), d64.as<uint64_t>(), nbuckets, ck, cv,
+                                       strip_mask, stride2);
+                else
+                    hipLaunchKernelGGL((k_compact<W, false>), dim3(blocks), dim3(256), 0, ctx->stream, bufB.as<Key<W>>(),
+                                       (const uint32_t *)nullptr, cboff, dcount.as<uint32_t>(), d64.as<uint64_t>(), nbuckets, ck,
+                                       (uint32_t *)nullptr, strip_mask, stride2);
+            }
             check_launch("k_compact");
         }
         if (extra.n) {

@@ -25,7 +25,7 @@ for it in range(R):
 dt = (time.time() - t0) / R
 print(f"k={k} n={n} distinct={nn} ms/step={dt*1e3:.2f}  (each: {' '.join('%.2f' % e for e in each)})")
 print("  memory:", ctx.memory_stats())
-fams = ["k_sk_part1", "k_sk_part2_hist", "k_sk_part2", "k_sk_dedup", "k_part_reads_narrow", "k_part_narrow2", "k_part_reads", "k_part_l2", "k_bucket_hash32", "k_bucket_hash", "k_bucket_hashidx", "k_part_l1", "k_bucket_dist", "k_bucket", "k_part_hist1", "k_part_hist2", "stat_superk_records", "stat_superk_declined"]
+fams = ["k_sk_part1", "k_sk_part2_hist", "k_sk_part2", "k_sk_dedup", "k_part_reads_narrow", "k_part_narrow2", "k_part_reads", "k_part_l2", "k_bucket_hash32", "k_bucket_hash", "k_bucket_hashidx", "k_part_l1", "k_bucket_dist", "k_bucket", "k_part_hist1", "k_part_hist2", "compact", "stat_superk_records", "stat_superk_declined"]
 for f in fams:
     d = ctx.profile_get(f); ms, cnt, by = d["ms"], d["launches"], d["bytes"]
     if cnt: print(f"  {f:24s} {ms/R:8.3f} ms/step  launches/step {cnt/R:5.1f}  bytes/step {by/R/1e9:8.3f} GB")
