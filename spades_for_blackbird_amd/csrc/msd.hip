@@ -1559,18 +1559,11 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
 #ifdef BBK_PHASE_PROF
     unsigned long long t_prev = clock64();
 #endif
-    for (uint32_t s = tid; s < kHashSlots; s += kHashThreads) {
-        tab[s] = EMPTY;
-        if (OP != 0) pay[s] = 0;
-    }
-    if (tid == 0) scan_tmp[14] = 0;
-    __syncthreads();
-    BBK_PH(4, 0, t_prev);  // table init
     uint64_t kk[kHashItems];
     uint32_t vv[kHashItems];
 #pragma unroll
-    for (int i = 0; i < kHashItems; ++i) {  // all loads first: independent, in flight together
-        const uint32_t p = (uint32_t)(i * kHashThreads + tid);
+    for (int i = 0; i < kHashItems; ++i) {  // all loads first: independent, in flight together -- and while the table
+        const uint32_t p = (uint32_t)(i * kHashThreads + tid);  // is cleared below
         kk[i] = EMPTY;
         vv[i] = 0;
         if (p < n) {
@@ -1578,6 +1571,13 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
             if (IN_VAL) vv[i] = vals[start + p];
         }
     }
+    for (uint32_t s = tid; s < kHashSlots; s += kHashThreads) {
+        tab[s] = EMPTY;
+        if (OP != 0) pay[s] = 0;
+    }
+    if (tid == 0) scan_tmp[14] = 0;
+    __syncthreads();
+    BBK_PH(4, 0, t_prev);  // table init
 #pragma unroll
     for (int i = 0; i < kHashItems; ++i) {
         if (kk[i] != EMPTY) {
@@ -2385,6 +2385,14 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(uint32_t *__re
         if (tid == 0) A.dcount[b] = 0xFFFFFFFFu;
         return;
     }
+    uint32_t kk[kNwHashItems], vv[kNwHashItems];
+#pragma unroll
+    for (int i = 0; i < kNwHashItems; ++i) {  // (the loads are in flight while the table is cleared)
+        const uint32_t p = (uint32_t)(i * kNwHashThreads + tid);
+        const uint32_t at = start + (p < n ? p : n - 1u);
+        kk[i] = buf[at];
+        vv[i] = IN_VAL ? vals[at] : 0u;
+    }
     for (uint32_t s = tid; s < kNwHashSlots; s += kNwHashThreads) {
         tab[s] = EMPTY;
         if (OP != 0) pay[s] = 0;
@@ -2392,14 +2400,6 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(uint32_t *__re
     if (tid < 4) scan_tmp[12 + tid] = 0;
     __syncthreads();
     BBK_PH(4, 0, t_prev);  // table cleared
-    uint32_t kk[kNwHashItems], vv[kNwHashItems];
-#pragma unroll
-    for (int i = 0; i < kNwHashItems; ++i) {
-        const uint32_t p = (uint32_t)(i * kNwHashThreads + tid);
-        const uint32_t at = start + (p < n ? p : n - 1u);
-        kk[i] = buf[at];
-        vv[i] = IN_VAL ? vals[at] : 0u;
-    }
 #ifdef BBK_PHASE_PROF
 #pragma unroll
     for (int i = 0; i < kNwHashItems; ++i) asm volatile("" : "+v"(kk[i]));
