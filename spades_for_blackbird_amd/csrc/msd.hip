@@ -1015,6 +1015,28 @@ __device__ __forceinline__ void bucket_reduce(Key<W> *skeys, uint32_t *svals, ui
         // conditional blocks of the store loop below and makes every store wait for the one before
         asm volatile("" : "+v"(ostart));
     }
+    if constexpr (OP == 0) {
+        // No payload: the distinct keys go back into LDS at their place in the result (a place at or before the thread's
+        // own records, all of which are in registers by now) and leave it with coalesced stores -- 512 contiguous bytes
+        // per wave instruction.  Straight from the blocked ownership every lane stored its ITEMS keys 8 ITEMS bytes from
+        // its neighbour's: 64 separate pieces per instruction.
+        int seg = (int)excl - 1;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            if (p0 + i < n && (headbits & (1u << i))) {
+                ++seg;
+                Key<W> kx = mine[i];
+                if (A.sorted_keys) kx.w[0] &= A.strip_mask;
+                key_store<W>(&skeys[seg], kx);
+            }
+        }
+        __syncthreads();
+        Key<W> *dstk = A.sorted_keys ? reinterpret_cast<Key<W> *>(A.sorted_keys) + ostart : buf + start;
+        for (uint32_t s = tid; s < total; s += NT) key_store<W>(&dstk[s], key_load<W>(&skeys[s]));
+        if (tid == 0 && A.sorted_keys && total != n) atomicOr(A.dup_flag, 1u);
+        if (tid == 0) A.dcount[b] = total;
+        return;
+    }
     uint32_t *acc = reinterpret_cast<uint32_t *>(skeys);  // CAP u32 fit in the key buffer
     if (OP != 0) {
         for (uint32_t s = tid; s < total; s += NT) acc[s] = 0;
