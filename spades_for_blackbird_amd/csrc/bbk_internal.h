@@ -147,6 +147,9 @@ struct bbk_ctx {
     bool own_stream = false;
     bool profiling = false;
     int num_cus = 256;
+    // XCDs the workgroups of a launch are seen to run on (HW_REG_XCC_ID of a probe launch at context creation): the
+    // per-XCD fill fronts of the partition kernels assume eight; anything else (a partitioned device) turns them off
+    int num_xcds = 8;
     // pending (start, stop, family, bytes) event pairs; resolved lazily
     struct Pending {
         hipEvent_t a, b;

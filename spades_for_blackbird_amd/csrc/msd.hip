@@ -2894,7 +2894,7 @@ struct MsdRunner {
         // when adjacent runs ALWAYS come from different XCDs.  The kernel itself: 3.64 -> 2.94 ms (same call, round 3;
         // in round 2 its arithmetic took as long as the stores and hid the gain: 3.96 -> 3.79).  BBK_XCD_SLOTS=0: A/B.
         static const bool use_xcd = !(getenv("BBK_XCD_SLOTS") && atoi(getenv("BBK_XCD_SLOTS")) == 0);
-        const int xs = (slots && use_xcd) ? 3 : 0;
+        const int xs = (slots && use_xcd && ctx->num_xcds == 8) ? 3 : 0;
         const uint32_t nsub = nb1 << xs;  // level-1 cursors = level-2 input segments
         const uint32_t sub_cap = xs ? ((uint32_t)((double)N / nsub * 1.06) + 2048u) | 1u : 0u;
         const uint32_t seg_cap = !slots ? 0u

@@ -1214,6 +1214,13 @@ extern "C" {
 const char *bbk_last_error(void) { return bbk::get_error(); }
 const char *bbk_version(void) { return "bbk 0.1 (gfx950)"; }
 
+// which XCDs the workgroups of a launch land on (one bit per HW_REG_XCC_ID value seen)
+__global__ void k_xcd_probe(uint32_t *mask) {
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) atomicOr(mask, 1u << (xcc & 15u));
+}
+
 int bbk_ctx_create(int device, bbk_ctx **out) {
     return bbk::guarded([&] {
         BBK_REQUIRE(out != nullptr, BBK_ERR_ARG, "bbk_ctx_create: out is NULL");
@@ -1231,6 +1238,18 @@ int bbk_ctx_create(int device, bbk_ctx **out) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
         BBK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
+        {
+            uint32_t *d_mask = nullptr, h_mask = 0;
+            if (hipMalloc(&d_mask, 4) == hipSuccess) {
+                (void)hipMemsetAsync(d_mask, 0, 4, c->stream);
+                hipLaunchKernelGGL(k_xcd_probe, dim3(4096), dim3(64), 0, c->stream, d_mask);
+                if (hipMemcpyAsync(&h_mask, d_mask, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                    hipStreamSynchronize(c->stream) == hipSuccess && h_mask)
+                    c->num_xcds = __builtin_popcount(h_mask);
+                (void)hipFree(d_mask);
+            }
+            (void)hipGetLastError();
+        }
         *out = c;
     });
 }

@@ -1033,7 +1033,7 @@ bool superk_run(bbk_ctx *ctx, const bbk_reads *rd, unsigned k, int op, DevBuf &o
     P.P1 = P1;
     P.P2 = P2;
     static const bool xcd_slots = !(getenv("BBK_XCD_SLOTS") && atoi(getenv("BBK_XCD_SLOTS")) == 0);
-    if (xcd_slots) {  // eight sub-slots, each with the slack of a slot of its size
+    if (xcd_slots && ctx->num_xcds == 8) {  // eight sub-slots, each with the slack of a slot of its size
         P.sub1 = (uint32_t)((slot1_64 + 7) / 8) + (es1 ? 2u : 512u);
         P.slot1 = 8u * P.sub1;
         P.tps_sub = (P.sub1 + kSk2Tile - 1) / kSk2Tile;
