@@ -3082,8 +3082,9 @@ struct MsdRunner {
         static const bool xcd_tiles = !(getenv("BBK_XCD_TILES") && atoi(getenv("BBK_XCD_TILES")) == 0);
         uint32_t nwg2 = ntiles2;  // workgroups of the level-2 kernel
         DevBuf xstart_d;
-        if (slots && xcd_tiles && ntiles2) {
-            std::vector<uint32_t> xstart(nsub);
+        std::vector<uint32_t> xstart;  // (lives to the end of the call: the copy below is asynchronous)
+        if (xcd_tiles && ntiles2) {  // (exact mode too: its histogram pass keeps the plain order, see desc2h)
+            xstart.resize(nsub);
             uint32_t per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (uint32_t s2 = 0; s2 < nsub; ++s2) {
                 uint32_t &c = per_xcd[(s2 >> xs) & 7u];
@@ -3093,7 +3094,6 @@ struct MsdRunner {
             nwg2 = 8u * *std::max_element(per_xcd, per_xcd + 8);
             xstart_d.alloc((size_t)nsub * 4);
             BBK_HIP(hipMemcpyAsync(xstart_d.p, xstart.data(), (size_t)nsub * 4, hipMemcpyHostToDevice, ctx->stream));
-            BBK_HIP(hipStreamSynchronize(ctx->stream));  // xstart is a local
         }
         DevBuf desc2((size_t)nwg2 * sizeof(uint4) + 16);
         if (ntiles2) {
@@ -3111,6 +3111,14 @@ struct MsdRunner {
             check_launch("k_tile_desc");
         }
         M2.desc = desc2.as<uint4>();
+        // exact mode: the histogram kernel walks 16 consecutive tiles per workgroup and wants them in plain order
+        DevBuf desc2h;
+        if (!slots && xstart_d.p && !narrow) {
+            desc2h.alloc((size_t)ntiles2 * sizeof(uint4) + 16);
+            hipLaunchKernelGGL(k_tile_desc, dim3((ntiles2 + 255) / 256), dim3(256), 0, ctx->stream, M2, seg_nb2.as<uint32_t>(),
+                               seg_bin.as<uint32_t>(), kPartTileK, xs, (const uint32_t *)nullptr, desc2h.as<uint4>());
+            check_launch("k_tile_desc");
+        }
         DevBuf hist2((size_t)nbuckets * 4 + 16), boff(((size_t)nbuckets + 1) * 4 + 16);
         const uint64_t nB = slots ? (uint64_t)nbuckets * stride2 : N;
         if (slots) BBK_REQUIRE(nB + N < (1ull << 32), BBK_ERR_INTERNAL, "slot layout exceeds 32-bit offsets");
@@ -3118,8 +3126,12 @@ struct MsdRunner {
         if (need_vbuf) valB.alloc(nB * 4);
         if (!slots) {
             BBK_HIP(hipMemsetAsync(hist2.p, 0, (size_t)nbuckets * 4 + 16, ctx->stream));
-            launch_part<false, true>("k_part_hist2", (double)N * rec, ntiles2, bufA.as<Key<W>>(), nullptr, M2, L2,
-                                     hist2.as<uint32_t>(), nullptr, nullptr, nullptr);
+            {
+                TileMap M2h = M2;
+                if (desc2h.p) M2h.desc = desc2h.as<uint4>();
+                launch_part<false, true>("k_part_hist2", (double)N * rec, ntiles2, bufA.as<Key<W>>(), nullptr, M2h, L2,
+                                         hist2.as<uint32_t>(), nullptr, nullptr, nullptr);
+            }
             DevBuf h64(((size_t)nbuckets + 1) * 8);
             hipLaunchKernelGGL(k_u32_to_u64, dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream,
                                hist2.as<uint32_t>(), (uint64_t)nbuckets, h64.as<uint64_t>(), 0u);
