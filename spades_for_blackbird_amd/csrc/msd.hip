@@ -2572,6 +2572,7 @@ struct MsdRunner {
     bool slots_ok = getenv("BBK_NO_SLOTS") == nullptr;  // histogram-free slot mode allowed (HASH prefix)
     bool kslots_ok = getenv("BBK_NO_KSLOTS") == nullptr;  // ... and for the ordering pass of a distinct key array
     bool never_decline = false;  // finish whatever overflows bucket by bucket on the LSD path instead of declining
+    bool even_part = false;      // the call sorts a materialised range of an expanded input (run_level0): key slots apply
     bool assume_distinct = false;  // caller's hint (key arrays, KEYS / REF prefix): duplicates are not expected
     unsigned expand_k = 0;         // key-array input holds CANONICAL k-mers of this length: both strands are generated
     bool expand_tag = false;       // ... with the XXH3 bucket tag above the k-mer (the runner's k is then k + 2)
@@ -2881,8 +2882,10 @@ struct MsdRunner {
         // (only for EXPANDED input: both strands of a set spread evenly over the key space; a canonical set does not --
         // its last base is A four times as often as T -- and 119 of 512 segments overflowed their slots in every
         // extension-index build: 3.8 ms of a 30 ms build spent on an attempt that never holds)
-        const bool kslots = kslots_ok && slots_ok && !has_dst && !from_reads && !ranged && assume_distinct && expand_k != 0 &&
-                            (dmode == MSD_KEYS || dmode == MSD_REF) && nb1 > 1 && N >= slots_min &&
+        // (even_part: a materialised range of an expanded input -- run_level0 -- is as evenly spread, holds exactly
+        // sel.est records and writes into its place of the final array)
+        const bool kslots = kslots_ok && slots_ok && (even_part || (!has_dst && !ranged && expand_k != 0)) && !from_reads &&
+                            assume_distinct && (dmode == MSD_KEYS || dmode == MSD_REF) && nb1 > 1 && N >= slots_min &&
                             getenv("BBK_NO_DIRECT") == nullptr && (double)N / fill * 1.1 + (double)N < 4.2e9;
         const bool slots = hslots || kslots;
         BBK_REQUIRE(!narrow || slots, BBK_ERR_INTERNAL, "narrow records need the slot mode");
@@ -3813,8 +3816,17 @@ struct MsdRunner {
                 MsdOutput part;
                 Dst dst{out.keys.as<char>() + D * rec, out.vals.p ? out.vals.as<uint32_t>() + D : nullptr};
                 const double t1 = wall();
-                const int rv = run(nullptr, buf0.as<char>() + (size_t)off[j] * rec, has_val ? val0.as<uint32_t>() + off[j] : nullptr,
-                                   sr.est, false, part, sr, nullptr, dst);
+                // ranges of an expanded (both-strand) input spread as evenly as the whole: the key slots of the ordering
+                // pass apply (no histogram passes, XCD-local fill fronts); should they not hold, the exact mode redoes it
+                even_part = ek != 0 && getenv("BBK_NO_PART_KSLOTS") == nullptr;
+                int rv = run(nullptr, buf0.as<char>() + (size_t)off[j] * rec, has_val ? val0.as<uint32_t>() + off[j] : nullptr,
+                             sr.est, false, part, sr, nullptr, dst);
+                if (rv == 4) {
+                    kslots_ok = false;
+                    rv = run(nullptr, buf0.as<char>() + (size_t)off[j] * rec, has_val ? val0.as<uint32_t>() + off[j] : nullptr,
+                             sr.est, false, part, sr, nullptr, dst);
+                }
+                even_part = false;
                 if (verbose) fprintf(stderr, "[bbk] key range (materialised): %.3f s\n", wall() - t1);
                 BBK_REQUIRE(rv == 1, BBK_ERR_INTERNAL, "a materialised range did not sort (%d)", rv);
                 D += part.n;
