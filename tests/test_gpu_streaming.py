@@ -105,6 +105,15 @@ def test_pushed_batches_with_forced_range_passes():
     assert "prefix mode 2" in err, "the REF-prefix range passes (16-byte keys, final_kmers order) did not run"
 
 
+def test_range_passes_with_slot_mode():
+    """forced range passes AND the histogram-free slot modes on small inputs: the materialised ranges of stage B (level-0
+    partition of the both-strand set) take the key slots of the ordering pass -- and whatever does not hold there (this
+    input has poly-A and ACGT-repeat reads: an uneven key space) goes back to the exact mode, range by range"""
+    err = _run({"BBK_MERGE_MIN": "0", "BBK_PASS_LIMIT": "30000", "BBK_SLOTS_MIN": "0"}, 2500, 15000, (21, 32, 55))
+    assert "level 0" in err, "no level-0 partition ran"
+    assert "msd key slots" in err, "the key slots were never tried"
+
+
 def test_slot_mode_with_pushed_batches():
     """the histogram-free slot mode + spill reprocessing on every pushed batch and on the merges"""
     _run({"BBK_MERGE_MIN": "0", "BBK_SLOTS_MIN": "0"}, 3000, 20000, (21, 33))
