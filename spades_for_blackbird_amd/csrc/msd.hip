@@ -1600,6 +1600,8 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
     if (tid == 0) scan_tmp[14] = 0;
     __syncthreads();
     BBK_PH(4, 0, t_prev);  // table init
+    uint32_t firsts = 0;  // bit i: record i of this lane was the first of its key in the table
+    static_assert(kHashItems <= 32, "one bit per record of a lane");
 #pragma unroll
     for (int i = 0; i < kHashItems; ++i) {
         if (kk[i] != EMPTY) {
@@ -1614,6 +1616,7 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
             uint32_t probes = 0;
             for (;;) {
                 const unsigned long long old = atomicCAS(&tab[slot], EMPTY, (unsigned long long)kk[i]);
+                if (old == EMPTY) firsts |= 1u << i;
                 if (old == EMPTY || old == kk[i]) break;
                 slot = (slot + 1) & (kHashSlots - 1);
                 if (kHashItems * kHashThreads > (int)(kHashSlots * 3 / 4) && ++probes > A.max_probes) {
@@ -1636,8 +1639,12 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
     // consecutive 8-byte slots: no LDS bank conflicts; the output order is free, the set is unsorted)
     constexpr int SPT = kHashSlots / kHashThreads;
     uint32_t cnt = 0;
+    if constexpr (OP == 0) {
+        cnt = (uint32_t)__popc(firsts);  // no payload to fetch: whoever put a key into the table writes it out
+    } else {
 #pragma unroll
-    for (int j = 0; j < SPT; ++j) cnt += tab[j * kHashThreads + tid] != EMPTY ? 1u : 0u;
+        for (int j = 0; j < SPT; ++j) cnt += tab[j * kHashThreads + tid] != EMPTY ? 1u : 0u;
+    }
     uint32_t incl = cnt;
     incl = wave_scan_incl(incl);
     if (lane == 63) scan_tmp[wave] = incl;
@@ -1648,13 +1655,20 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
     uint32_t *ovals = vals;
     const uint32_t obase = start;
     uint32_t o = obase + wbase + incl - cnt;
+    if constexpr (OP == 0) {
 #pragma unroll
-    for (int j = 0; j < SPT; ++j) {
-        const unsigned long long key = tab[j * kHashThreads + tid];
-        if (key != EMPTY) {
-            obuf[o].w[0] = key;
-            if (OP != 0) ovals[o] = pay[j * kHashThreads + tid];
-            ++o;
+        for (int i = 0; i < kHashItems; ++i) {
+            if (firsts & (1u << i)) obuf[o++].w[0] = kk[i];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const unsigned long long key = tab[j * kHashThreads + tid];
+            if (key != EMPTY) {
+                obuf[o].w[0] = key;
+                ovals[o] = pay[j * kHashThreads + tid];
+                ++o;
+            }
         }
     }
     BBK_PH(4, 2, t_prev);  // compaction + output
@@ -2427,6 +2441,7 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(uint32_t *__re
     for (int i = 0; i < kNwHashItems; ++i) asm volatile("" : "+v"(kk[i]));
     BBK_PH(4, 1, t_prev);  // records loaded
 #endif
+    uint32_t firsts = 0;  // bit i: record i of this lane was the first of its key in the table
 #pragma unroll
     for (int i = 0; i < kNwHashItems; ++i) {
         const uint32_t p = (uint32_t)(i * kNwHashThreads + tid);
@@ -2442,6 +2457,7 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(uint32_t *__re
             uint32_t probes = 0;
             for (;;) {
                 const uint32_t old = atomicCAS(&tab[slot], EMPTY, kk[i]);
+                if (old == EMPTY) firsts |= 1u << i;
                 if (old == EMPTY || old == kk[i]) break;
                 slot = (slot + 1) & (kNwHashSlots - 1);
                 if (++probes > A.max_probes) {
@@ -2462,8 +2478,12 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(uint32_t *__re
     }
     constexpr int SPT = kNwHashSlots / kNwHashThreads;
     uint32_t cnt = 0;
+    if constexpr (OP == 0) {
+        cnt = (uint32_t)__popc(firsts);  // no payload to fetch: whoever put a key into the table writes it out -- no walk
+    } else {                             // over the 8192 slots
 #pragma unroll
-    for (int j = 0; j < SPT; ++j) cnt += tab[j * kNwHashThreads + tid] != EMPTY ? 1u : 0u;
+        for (int j = 0; j < SPT; ++j) cnt += tab[j * kNwHashThreads + tid] != EMPTY ? 1u : 0u;
+    }
     uint32_t incl = cnt;
     incl = wave_scan_incl(incl);
     if (lane == 63) scan_tmp[wave] = incl;
@@ -2475,15 +2495,23 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(uint32_t *__re
     // pass over the bucket counts gives the offsets of the dense result and k_compact_narrow widens them into it.
     // (Until round 3 every bucket reserved its place in the result with an atomicAdd on ONE counter: 227 210 buckets at
     // BASELINE configs[1], served one after the other at ~11 ns each -- 2.6 ms of the kernel's 2.8,
-    // tools/probes/single_counter_probe.hip.)  Every record of the bucket has been read before the first barrier above.
+    // tools/probes/single_counter_probe.hip.)  Every record of the bucket has been loaded AND used before the barrier
+    // that follows the insertions: nothing is overwritten before it has been read.
     uint32_t o = start + wbase + incl - cnt;
+    if constexpr (OP == 0) {
 #pragma unroll
-    for (int j = 0; j < SPT; ++j) {
-        const uint32_t rec = tab[j * kNwHashThreads + tid];
-        if (rec != EMPTY) {
-            buf[o] = rec;
-            if (OP != 0) vals[o] = pay[j * kNwHashThreads + tid];
-            ++o;
+        for (int i = 0; i < kNwHashItems; ++i) {
+            if (firsts & (1u << i)) buf[o++] = kk[i];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const uint32_t rec = tab[j * kNwHashThreads + tid];
+            if (rec != EMPTY) {
+                buf[o] = rec;
+                vals[o] = pay[j * kNwHashThreads + tid];
+                ++o;
+            }
         }
     }
     BBK_PH(4, 3, t_prev);  // compaction + output
