@@ -2936,8 +2936,7 @@ struct MsdRunner {
         // fill front sits in the same HBM channel (level-2 scatter measured 10 % slower)
         const size_t rec_ab = narrow ? 4 : rec;  // record width between the levels
         const uint32_t stride2 = cap2 + (uint32_t)(256 / rec_ab);
-        DevBuf spill_k, spill_v, spill_n;  // spill_n: u32 counters [0] spilled records [1] records written by the
-                                           // dedup kernels [2] buckets left to the caller
+        DevBuf spill_k, spill_v, spill_n;  // spill_n: u32 counters [0] spilled records [1] unused [2] buckets left to the caller
         const uint32_t spill_cap = slots ? (uint32_t)(N / 8 + 65536) : 0u;
         if (slots) {
             spill_k.alloc((size_t)spill_cap * rec);
@@ -3342,7 +3341,7 @@ struct MsdRunner {
             bucket_dispatch<false>(nbuckets, bufB.as<Key<W>>(), valB.as<uint32_t>(), A, bb);
             fetch_flags();
         }
-        const uint32_t n_spill = ctr[0], n_direct = ctr[1], n_flag = ctr[2];
+        const uint32_t n_spill = ctr[0], n_flag = ctr[2];
         if (n_flag > kFlagCap) {  // tens of thousands of overflowing buckets: not an input for this path
             if (verbose) fprintf(stderr, "[bbk] msd: %u buckets overflow\n", n_flag);
             return slots ? 3 : 0;
