@@ -1871,8 +1871,13 @@ __global__ void k_kmers_per_read2(const uint32_t *__restrict__ len, const uint64
 // narrow stage A kernels (4-byte records, see "narrow records" above): level 1 from reads, level 2, dedup
 // ------------------------------------------------------------------------------------------
 constexpr int kNwThreads = 1024;
-constexpr int kNwRounds = 2;      // consecutive chunks of 8 k-mer positions per lane (the last 64 lanes of a full tile idle)
-constexpr int kNwChunks = 1920;   // chunks of a level-1 tile: 15360 records = 60 KB staged, runs of ~15 per bin;
+#ifndef BBK_NW_ROUNDS  // (experiments: -DBBK_NW_ROUNDS=4 -DBBK_NW_CHUNKS=3840 -DBBK_NW_WAVES=4 is one workgroup per CU with a 120 KB stage)
+#define BBK_NW_ROUNDS 2
+#define BBK_NW_CHUNKS 1920
+#define BBK_NW_WAVES 8
+#endif
+constexpr int kNwRounds = BBK_NW_ROUNDS;  // consecutive chunks of 8 k-mer positions per lane (the last 64 lanes of a full tile idle)
+constexpr int kNwChunks = BBK_NW_CHUNKS;  // chunks of a level-1 tile: 15360 records = 60 KB staged, runs of ~15 per bin;
                                   // (x 8 records) with the tables 77 KB of LDS: two workgroups per CU
 // with a payload (one mask byte per record: the extension index) the same tile would take 94 KB = ONE workgroup per CU
 // (measured 8.4 ms against 3.8 ms without payload); 1536 chunks = 12 288 records x 5 bytes + tables = 78 KB
@@ -2023,7 +2028,7 @@ __device__ __forceinline__ void nw_extract(const ReadSrc &S, const PartLevel &L,
 // r = #marks at or before pos - 1 (a 64-position word of marks is exactly what a wave handles per step).  What a
 // store needs of its bin -- global offset and room left in the slot -- sits in one 8-byte entry indexed by r.
 template <bool HAS_VAL>
-__global__ __launch_bounds__(kNwThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_part_reads_narrow(ReadSrc S, PartLevel L, uint32_t ntiles,
+__global__ __launch_bounds__(kNwThreads) __attribute__((amdgpu_waves_per_eu(BBK_NW_WAVES, BBK_NW_WAVES))) void k_part_reads_narrow(ReadSrc S, PartLevel L, uint32_t ntiles,
                                                                  uint32_t *__restrict__ cursor,
                                                                  uint32_t *__restrict__ out, uint32_t *__restrict__ vout) {
     constexpr int NT = kNwThreads, CH = 8, MAXB = kNwBins1, ITEMS = CH * NwCfg<HAS_VAL>::ROUNDS;
