@@ -2504,6 +2504,10 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(uint32_t *__re
     // that follows the insertions: nothing is overwritten before it has been read.
     uint32_t o = start + wbase + incl - cnt;
     if constexpr (OP == 0) {
+        // (the loaded records are awaited here by every lane: the insertion loop used them under `p < n` only, and the
+        // compiler would otherwise wait for them -- vmcnt 0 -- in front of every store below)
+#pragma unroll
+        for (int i = 0; i < kNwHashItems; ++i) asm volatile("" : "+v"(kk[i]));
 #pragma unroll
         for (int i = 0; i < kNwHashItems; ++i) {
             if (firsts & (1u << i)) buf[o++] = kk[i];
