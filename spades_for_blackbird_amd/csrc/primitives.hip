@@ -616,24 +616,35 @@ __global__ __launch_bounds__(kThreads) void k_scan_apply(const uint64_t *__restr
     }
 }
 
+// One level of the scan: block sums, (recursively) their exclusive scan in place, then the blocks.  Nothing waits on the
+// host in between: the block-sum buffers of every level live in `keep` until the caller has synchronised once, and the
+// grand total is parked in *d_total on the way down.
+static void scan_level(bbk_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n, std::vector<DevBuf> &keep,
+                       uint64_t *d_total) {
+    const uint64_t nb = (n + kScanTile - 1) / kScanTile;
+    keep.emplace_back((nb + 1) * sizeof(uint64_t));
+    uint64_t *bsum = keep.back().as<uint64_t>();
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream, in, n, bsum);
+    check_launch("k_scan_reduce");
+    if (nb == 1) {
+        BBK_HIP(hipMemcpyAsync(d_total, bsum, sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+        BBK_HIP(hipMemsetAsync(bsum, 0, sizeof(uint64_t), ctx->stream));
+    } else {
+        scan_level(ctx, bsum, bsum, nb, keep, d_total);
+    }
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream, in, out, n, bsum);
+    check_launch("k_scan_apply");
+}
+
 uint64_t exclusive_scan_u64(bbk_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t n) {
     if (n == 0) return 0;
-    const uint64_t nb = (n + kScanTile - 1) / kScanTile;
-    DevBuf bsum((nb + 1) * sizeof(uint64_t));
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream, in, n, bsum.as<uint64_t>());
-    check_launch("k_scan_reduce");
-    uint64_t total;
-    if (nb == 1) {
-        BBK_HIP(hipMemcpyAsync(&total, bsum.p, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        BBK_HIP(hipMemsetAsync(bsum.p, 0, sizeof(uint64_t), ctx->stream));
-        BBK_HIP(hipStreamSynchronize(ctx->stream));
-    } else {
-        total = exclusive_scan_u64(ctx, bsum.as<uint64_t>(), bsum.as<uint64_t>(), nb);
-    }
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kThreads), 0, ctx->stream, in, out, n,
-                       bsum.as<uint64_t>());
-    check_launch("k_scan_apply");
-    BBK_HIP(hipStreamSynchronize(ctx->stream));  // bsum is freed on return
+    std::vector<DevBuf> keep;
+    keep.reserve(8);  // levels: log_{tile}(n)
+    DevBuf dt(16);
+    scan_level(ctx, in, out, n, keep, dt.as<uint64_t>());
+    uint64_t total = 0;
+    BBK_HIP(hipMemcpyAsync(&total, dt.p, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    BBK_HIP(hipStreamSynchronize(ctx->stream));  // one wait per scan (it was one per level): the buffers go back now
     return total;
 }
 
