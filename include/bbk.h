@@ -323,6 +323,11 @@ int bbk_group_gather_kmers(bbk_group *g, int rank, bbk_ctx *ctx, const bbk_kmers
  * spent mapping, and the device's free / total bytes as the driver reports them.  Any pointer may be NULL. */
 int bbk_ctx_memory_stats(bbk_ctx *ctx, uint64_t *mapped_now, uint64_t *mapped_total, double *map_seconds,
                          uint64_t *device_free, uint64_t *device_total);
+/* What the engine found on the device at bbk_ctx_create: compute units, and the XCDs a probe launch's workgroups were seen
+ * on (HW_REG_XCC_ID).  The partition kernels keep one fill front per (segment, XCD) and deal level-2 tiles to the XCDs by
+ * segment when that is eight (an MI355X in SPX mode); any other value -- a partitioned device -- switches both off.
+ * Placement only: results never depend on it.  (Diagnostics; no reference counterpart.) */
+int bbk_ctx_device_info(bbk_ctx *ctx, int *num_cus, int *num_xcds);
 /* XXH3 bucket boundaries of a set stored in the final_kmers order: h_offsets[b] = first record of bucket b (b = 0..16,
  * h_offsets[16] = size); what a writer that merges several shards into one final_kmers file needs
  * (KMerDiskStorage::merge, kmer_index_builder.hpp:168-181) */

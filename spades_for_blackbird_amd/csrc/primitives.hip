@@ -1316,6 +1316,14 @@ int bbk_ctx_memory_stats(bbk_ctx *ctx, uint64_t *mapped_now, uint64_t *mapped_to
     });
 }
 
+int bbk_ctx_device_info(bbk_ctx *ctx, int *num_cus, int *num_xcds) {
+    return bbk::guarded([&] {
+        BBK_REQUIRE(ctx != nullptr, BBK_ERR_ARG, "bbk_ctx_device_info: ctx is NULL");
+        if (num_cus) *num_cus = ctx->num_cus;
+        if (num_xcds) *num_xcds = ctx->num_xcds;
+    });
+}
+
 int bbk_ctx_synchronize(bbk_ctx *ctx) {
     return bbk::guarded([&] {
         BBK_REQUIRE(ctx != nullptr, BBK_ERR_ARG, "bbk_ctx_synchronize: ctx is NULL");

@@ -27,7 +27,7 @@ SYMBOLS = [
     "bbk_unitigs_vertices", "bbk_unitigs_links", "bbk_unitigs_export", "bbk_unitigs_export_links",
     "bbk_unitigs_write_gfa", "bbk_unitigs_write_fasta", "bbk_unitigs_write_fastg", "bbk_unitigs_write_spades", "bbk_unitigs_free",
     "bbk_group_create", "bbk_group_size", "bbk_group_device", "bbk_group_destroy", "bbk_group_abort", "bbk_group_exchange_kmers",
-    "bbk_group_exchange_extindex", "bbk_group_gather_extindex", "bbk_group_gather_kmers", "bbk_ctx_memory_stats", "bbk_kmerset_bucket_offsets",
+    "bbk_group_exchange_extindex", "bbk_group_gather_extindex", "bbk_group_gather_kmers", "bbk_ctx_memory_stats", "bbk_ctx_device_info", "bbk_kmerset_bucket_offsets",
 ]
 
 
@@ -174,6 +174,7 @@ def load_library():
     L.bbk_group_gather_extindex.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(vp)]
     L.bbk_group_gather_kmers.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.POINTER(vp)]
     L.bbk_ctx_memory_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64)]
+    L.bbk_ctx_device_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.bbk_kmerset_bucket_offsets.argtypes = [vp, vp, vp]
     _LIB = L
     return L
@@ -235,6 +236,12 @@ class Context:
         _check(self._L.bbk_ctx_memory_stats(self._h, C.byref(a), C.byref(b), C.byref(sec), C.byref(f), C.byref(t)))
         return {"mapped_now": a.value, "mapped_total": b.value, "map_seconds": sec.value, "device_free": f.value,
                 "device_total": t.value}
+
+    def device_info(self):
+        """{'num_cus', 'num_xcds'}: what the engine found at context creation (8 XCDs switch the XCD-local fill fronts on)"""
+        a, b = C.c_int(), C.c_int()
+        _check(self._L.bbk_ctx_device_info(self._h, C.byref(a), C.byref(b)))
+        return {"num_cus": a.value, "num_xcds": b.value}
 
     def profile(self, on=True):
         _check(self._L.bbk_ctx_profile_enable(self._h, int(on)))

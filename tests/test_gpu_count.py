@@ -424,3 +424,36 @@ def test_direct_sorted_output_withdrawn(ctx, monkeypatch, capfd):
     err = capfd.readouterr().err
     if not any(os.environ.get(v) for v in ("BBK_DISABLE_MSD", "BBK_NO_DIRECT", "BBK_NO_DIST")):
         assert "direct output withdrawn" in err
+
+
+def test_device_info_and_xcd_switches(monkeypatch):
+    """bbk_ctx_device_info: an MI355X in SPX mode shows 256 CUs and 8 XCDs (what turns the XCD-local fill fronts on); the
+    result of a count does not depend on those switches (placement only)."""
+    import numpy as np
+    import spades_for_blackbird_amd as B
+    ctx = B.Context(0)
+    info = ctx.device_info()
+    assert info["num_cus"] > 0 and 1 <= info["num_xcds"] <= 16, info
+    import torch
+    if "MI355" in torch.cuda.get_device_name(0):
+        assert info == {"num_cus": 256, "num_xcds": 8}, info
+    r = ctx.reads_synth(300_000, read_len=150, genome_len=900_000, seed_reads=5)
+    monkeypatch.setenv("BBK_SLOTS_MIN", "0")
+    a = ctx.count(r, 21, B.BOTH_STRANDS | B.WITH_COUNTS).export(B.ORDER_REFERENCE_BUCKETS16, with_counts=True)
+    b55 = ctx.count(r, 55, B.BOTH_STRANDS).export(B.ORDER_REFERENCE_BUCKETS16)
+    assert len(a[0]) > 1_000_000
+    ctx.close()
+    # the switches are read once per process: the other setting runs in a child
+    import subprocess, sys, os, hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path.insert(0, %r); import spades_for_blackbird_amd as B; ctx = B.Context(0); "
+            "r = ctx.reads_synth(300000, read_len=150, genome_len=900000, seed_reads=5); "
+            "a = ctx.count(r, 21, B.BOTH_STRANDS | B.WITH_COUNTS).export(B.ORDER_REFERENCE_BUCKETS16, with_counts=True); "
+            "b = ctx.count(r, 55, B.BOTH_STRANDS).export(B.ORDER_REFERENCE_BUCKETS16); "
+            "print(hashlib.md5(a[0].tobytes()).hexdigest(), hashlib.md5(a[1].tobytes()).hexdigest(), hashlib.md5(b.tobytes()).hexdigest())" % root)
+    env = dict(os.environ, BBK_XCD_SLOTS="0", BBK_XCD_TILES="0", BBK_SLOTS_MIN="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    want = "%s %s %s" % (hashlib.md5(a[0].tobytes()).hexdigest(), hashlib.md5(a[1].tobytes()).hexdigest(),
+                         hashlib.md5(b55.tobytes()).hexdigest())
+    assert out.stdout.strip().splitlines()[-1] == want
