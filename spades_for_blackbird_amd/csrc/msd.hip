@@ -2029,6 +2029,8 @@ __device__ __forceinline__ void nw_extract(const ReadSrc &S, const PartLevel &L,
 // store needs of its bin -- global offset and room left in the slot -- sits in one 8-byte entry indexed by r.
 template <bool HAS_VAL>
 __global__ __launch_bounds__(kNwThreads) __attribute__((amdgpu_waves_per_eu(BBK_NW_WAVES, BBK_NW_WAVES))) void k_part_reads_narrow(ReadSrc S, PartLevel L, uint32_t ntiles,
+                                                                 const RdTile *__restrict__ tiles,  // = S.tiles: as an
+                                                                 // argument of its own the descriptor is a scalar load
                                                                  uint32_t *__restrict__ cursor,
                                                                  uint32_t *__restrict__ out, uint32_t *__restrict__ vout) {
     constexpr int NT = kNwThreads, CH = 8, MAXB = kNwBins1, ITEMS = CH * NwCfg<HAS_VAL>::ROUNDS;
@@ -2088,7 +2090,7 @@ __global__ __launch_bounds__(kNwThreads) __attribute__((amdgpu_waves_per_eu(BBK_
 
     uint32_t tile = blockIdx.x;
     if (tile >= ntiles) return;
-    RdTile T = S.tiles[tile];
+    RdTile T = tiles[tile];
     Pre Q{0, 0, 0, 0, 0};
     prefetch(T, Q);
     for (;;) {
@@ -2100,7 +2102,7 @@ __global__ __launch_bounds__(kNwThreads) __attribute__((amdgpu_waves_per_eu(BBK_
         const uint32_t tile_next = tile + gridDim.x;
         const bool more = tile_next < ntiles;  // uniform: every wave of the workgroup leaves the loop together
         RdTile Tn = T;
-        if (more) Tn = S.tiles[tile_next];
+        if (more) Tn = tiles[tile_next];
 
         const uint64_t c0 = (uint64_t)tile * NwCfg<HAS_VAL>::CHUNKS;
         const uint64_t left = S.n_chunks - c0;
@@ -3025,11 +3027,11 @@ struct MsdRunner {
                     if (has_val) {
                         auto fn = k_part_reads_narrow<true>;
                         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-                        hipLaunchKernelGGL(fn, dim3(grid), dim3(kNwThreads), sm, ctx->stream, S, L1, ntiles1, cur1.as<uint32_t>(), bufA.as<uint32_t>(), valA.as<uint32_t>());
+                        hipLaunchKernelGGL(fn, dim3(grid), dim3(kNwThreads), sm, ctx->stream, S, L1, ntiles1, S.tiles, cur1.as<uint32_t>(), bufA.as<uint32_t>(), valA.as<uint32_t>());
                     } else {
                         auto fn = k_part_reads_narrow<false>;
                         BBK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-                        hipLaunchKernelGGL(fn, dim3(grid), dim3(kNwThreads), sm, ctx->stream, S, L1, ntiles1, cur1.as<uint32_t>(), bufA.as<uint32_t>(), (uint32_t *)nullptr);
+                        hipLaunchKernelGGL(fn, dim3(grid), dim3(kNwThreads), sm, ctx->stream, S, L1, ntiles1, S.tiles, cur1.as<uint32_t>(), bufA.as<uint32_t>(), (uint32_t *)nullptr);
                     }
                     check_launch("k_part_reads_narrow");
                 }
