@@ -2029,7 +2029,7 @@ __device__ __forceinline__ void nw_extract(const ReadSrc &S, const PartLevel &L,
 // store needs of its bin -- global offset and room left in the slot -- sits in one 8-byte entry indexed by r.
 template <bool HAS_VAL>
 __global__ __launch_bounds__(kNwThreads) __attribute__((amdgpu_waves_per_eu(BBK_NW_WAVES, BBK_NW_WAVES))) void k_part_reads_narrow(ReadSrc S, PartLevel L, uint32_t ntiles,
-                                                                 const RdTile *__restrict__ tiles,  // = S.tiles: as an
+                                                                 const RdTile *__restrict__ tiles_arg,  // = S.tiles: as an
                                                                  // argument of its own the descriptor is a scalar load
                                                                  uint32_t *__restrict__ cursor,
                                                                  uint32_t *__restrict__ out, uint32_t *__restrict__ vout) {
@@ -2088,6 +2088,12 @@ __global__ __launch_bounds__(kNwThreads) __attribute__((amdgpu_waves_per_eu(BBK_
         Q.w1 = S.words[T.wbase + j1];
     };
 
+#ifdef BBK_NW_TILES_VIA_STRUCT  // (A/B: the descriptor through the pointer inside S -- a vector load + readfirstlane)
+    const RdTile *tiles = S.tiles;
+    (void)tiles_arg;
+#else
+    const RdTile *__restrict__ tiles = tiles_arg;
+#endif
     uint32_t tile = blockIdx.x;
     if (tile >= ntiles) return;
     RdTile T = tiles[tile];
