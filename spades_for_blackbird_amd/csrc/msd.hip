@@ -1015,6 +1015,7 @@ __device__ __forceinline__ void bucket_reduce(Key<W> *skeys, uint32_t *svals, ui
         // conditional blocks of the store loop below and makes every store wait for the one before
         asm volatile("" : "+v"(ostart));
     }
+#ifndef BBK_AB_BLOCKED_REDUCE  // (A/B: -DBBK_AB_BLOCKED_REDUCE stores straight from the blocked ownership, as before round 3)
     if constexpr (OP == 0) {
         // No payload: the distinct keys go back into LDS at their place in the result (a place at or before the thread's
         // own records, all of which are in registers by now) and leave it with coalesced stores -- 512 contiguous bytes
@@ -1037,6 +1038,7 @@ __device__ __forceinline__ void bucket_reduce(Key<W> *skeys, uint32_t *svals, ui
         if (tid == 0) A.dcount[b] = total;
         return;
     }
+#endif
     uint32_t *acc = reinterpret_cast<uint32_t *>(skeys);  // CAP u32 fit in the key buffer
     if (OP != 0) {
         for (uint32_t s = tid; s < total; s += NT) acc[s] = 0;
@@ -1546,6 +1548,11 @@ static size_t bucket_smem() {
 // ds_cmpst; with 50x coverage ~8 of 9 records find their key already there on the first probe.
 // ~30 instructions per record instead of 6 radix passes.  The distinct keys (+ reduced payload)
 // are written back in place in table order.
+#ifdef BBK_AB_TABLE_WALK  // (A/B: the distinct keys always collected by a walk over the table's slots, as before round 3)
+constexpr bool kHashDirectOut = false;
+#else
+constexpr bool kHashDirectOut = true;
+#endif
 constexpr int kHashThreads = 512;
 #ifndef BBK_HASH_ITEMS
 #define BBK_HASH_ITEMS 16
@@ -1639,7 +1646,7 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
     // consecutive 8-byte slots: no LDS bank conflicts; the output order is free, the set is unsorted)
     constexpr int SPT = kHashSlots / kHashThreads;
     uint32_t cnt = 0;
-    if constexpr (OP == 0) {
+    if constexpr (OP == 0 && kHashDirectOut) {
         cnt = (uint32_t)__popc(firsts);  // no payload to fetch: whoever put a key into the table writes it out
     } else {
 #pragma unroll
@@ -1655,7 +1662,7 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
     uint32_t *ovals = vals;
     const uint32_t obase = start;
     uint32_t o = obase + wbase + incl - cnt;
-    if constexpr (OP == 0) {
+    if constexpr (OP == 0 && kHashDirectOut) {
 #pragma unroll
         for (int i = 0; i < kHashItems; ++i) {
             if (firsts & (1u << i)) obuf[o++].w[0] = kk[i];
@@ -1666,7 +1673,7 @@ __global__ __launch_bounds__(kHashThreads) void k_bucket_hash(Key<1> *__restrict
             const unsigned long long key = tab[j * kHashThreads + tid];
             if (key != EMPTY) {
                 obuf[o].w[0] = key;
-                ovals[o] = pay[j * kHashThreads + tid];
+                if (OP != 0) ovals[o] = pay[j * kHashThreads + tid];
                 ++o;
             }
         }
@@ -2491,7 +2498,7 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(uint32_t *__re
     }
     constexpr int SPT = kNwHashSlots / kNwHashThreads;
     uint32_t cnt = 0;
-    if constexpr (OP == 0) {
+    if constexpr (OP == 0 && kHashDirectOut) {
         cnt = (uint32_t)__popc(firsts);  // no payload to fetch: whoever put a key into the table writes it out -- no walk
     } else {                             // over the 8192 slots
 #pragma unroll
@@ -2511,7 +2518,7 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(uint32_t *__re
     // tools/probes/single_counter_probe.hip.)  Every record of the bucket has been loaded AND used before the barrier
     // that follows the insertions: nothing is overwritten before it has been read.
     uint32_t o = start + wbase + incl - cnt;
-    if constexpr (OP == 0) {
+    if constexpr (OP == 0 && kHashDirectOut) {
         // (the loaded records are awaited here by every lane: the insertion loop used them under `p < n` only, and the
         // compiler would otherwise wait for them -- vmcnt 0 -- in front of every store below)
 #pragma unroll
@@ -2526,7 +2533,7 @@ __global__ __launch_bounds__(kNwHashThreads) void k_bucket_hash32(uint32_t *__re
             const uint32_t rec = tab[j * kNwHashThreads + tid];
             if (rec != EMPTY) {
                 buf[o] = rec;
-                vals[o] = pay[j * kNwHashThreads + tid];
+                if (OP != 0) vals[o] = pay[j * kNwHashThreads + tid];
                 ++o;
             }
         }
